@@ -1,0 +1,251 @@
+/*
+ * rupphash.h -- C ABI of librupphash_hip.so: the MI355X (gfx950) engine for the
+ * PDQ-hash + 256-bit Hamming-grouping hot path of Safari77/rupphash (phdupes).
+ *
+ * Each entry point names the reference interface it replaces (file:line in the
+ * reference tree).  The library is a drop-in for that path only; the reference's
+ * Rust modules keep their public signatures and call these functions through an
+ * `extern "C"` block (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every function returns 0 (RPH_OK) or a negative rph_status; nothing aborts
+ *   - plain pointers and sizes only; the caller owns every buffer
+ *   - one rph_ctx per process and GPU (one process per GPU; multi-GPU sharding is
+ *     done by the caller's launcher, see rupphash_amd/dist.py); a context is
+ *     thread-safe: calls on one context are serialised internally
+ *   - `*_dev` twins take DEVICE pointers and a hipStream_t (as void*), enqueue
+ *     asynchronously and never synchronise; host-pointer versions stage through
+ *     device memory and return when the result is in the caller's buffer
+ *   - there is no CPU fallback: if no gfx950 device is usable, rph_init fails
+ */
+#ifndef RUPPHASH_H
+#define RUPPHASH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPH_ABI_VERSION 1
+
+typedef enum rph_status {
+    RPH_OK = 0,
+    RPH_ERR_INVALID_ARG = -1,
+    RPH_ERR_NO_DEVICE = -2,     /* no HIP device / not gfx950 */
+    RPH_ERR_HIP = -3,           /* a HIP runtime call failed; rph_last_error() has the text */
+    RPH_ERR_OOM = -4,
+    RPH_ERR_UNSUPPORTED = -5,   /* e.g. w or h > 512: pre-downsample (pdqhash.rs:181-220) not built yet */
+    RPH_ERR_CAPACITY = -6       /* output capacity too small; the required count is still reported */
+} rph_status;
+
+typedef struct rph_ctx rph_ctx;
+
+/* ---- constants of the reference ---- */
+#define RPH_MAX_SIMILARITY_64 15u    /* hamminghash.rs:5  MAX_SIMILARITY_64  */
+#define RPH_MAX_SIMILARITY_256 63u   /* hamminghash.rs:8  MAX_SIMILARITY_256 */
+#define RPH_PDQ_MIN_QUALITY 50       /* scanner.rs:1588   PDQ_MIN_QUALITY    */
+#define RPH_PDQ_MIN_DIM 5u           /* pdqhash.rs:17     MIN_HASHABLE_DIM   */
+#define RPH_PDQ_MAX_DIM 512u         /* pdqhash.rs:19     DOWNSAMPLE_DIMS    */
+
+/* ---- lifecycle ---- */
+int rph_abi_version(void);
+/* Bind to HIP device `device` (ordinal within HIP_VISIBLE_DEVICES).  Fails with
+ * RPH_ERR_NO_DEVICE when the device is missing or is not gfx950. */
+int rph_init(int device, rph_ctx **ctx_out);
+int rph_shutdown(rph_ctx *ctx);
+/* Text of the last error raised on this thread (never NULL). */
+const char *rph_last_error(void);
+const char *rph_status_string(int status);
+/* name[64], compute-unit count, bytes of device memory */
+int rph_device_info(rph_ctx *ctx, char *name64, int *compute_units, uint64_t *total_mem);
+/* Block until all work queued on the context's own stream is done. */
+int rph_synchronize(rph_ctx *ctx);
+
+/* =====================================================================
+ * PDQ hashing  (reference: src/pdqhash.rs)
+ * ===================================================================== */
+
+/*
+ * Batch form of generate_pdq_features / generate_pdq (pdqhash.rs:166-201) +
+ * PdqFeatures::to_hash (:59-61) + generate_dihedral_hashes (:71-87).
+ *
+ * px: n images of w x h pixels, `channels` interleaved u8 samples per pixel
+ *     (1 = Luma8, borrowed as is pdqhash.rs:173; 3 = RGB8; 4 = RGBA8, alpha
+ *     ignored :279), row_stride bytes between rows, image_stride bytes between
+ *     images.  All images of a call share one geometry.
+ * Outputs (each nullable except hash32_out):
+ *   hash32_out   n x 32 bytes           to_hash() of the features
+ *   quality_out  n floats in [0,1]      second member of the reference's tuple
+ *   coeffs_out   n x 256 floats         PdqFeatures.coefficients, row-major i*16+j
+ *   dihedral_out n x 8 x 32 bytes       generate_dihedral_hashes(), reference slot order
+ *   valid_out    n bytes                1 = Some(..), 0 = None (w or h < 5, :167-169)
+ * w or h > 512 needs the reference's pre-downsample (third-party
+ * fast_image_resize, :181-220): not built yet -> RPH_ERR_UNSUPPORTED.
+ */
+int rph_pdq_hash_batch(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, uint32_t h,
+                       uint32_t channels, size_t row_stride, size_t image_stride,
+                       uint8_t *hash32_out, float *quality_out, float *coeffs_out,
+                       uint8_t *dihedral_out, uint8_t *valid_out);
+int rph_pdq_hash_batch_dev(rph_ctx *ctx, const void *d_px, uint32_t n, uint32_t w, uint32_t h,
+                           uint32_t channels, size_t row_stride, size_t image_stride,
+                           void *d_hash32, void *d_quality, void *d_coeffs, void *d_dihedral,
+                           void *d_valid, void *stream);
+
+/* PdqFeatures::to_hash (pdqhash.rs:59-61) and generate_dihedral_hashes (:71-87)
+ * for n stored coefficient vectors (n x 256 floats), e.g. features read back
+ * from the cache (scanner.rs:1270-1272).  hash32_out / dihedral_out nullable. */
+int rph_pdq_hashes_from_coeffs(rph_ctx *ctx, const float *coeffs, uint32_t n, uint8_t *hash32_out,
+                               uint8_t *dihedral_out);
+int rph_pdq_hashes_from_coeffs_dev(rph_ctx *ctx, const void *d_coeffs, uint32_t n, void *d_hash32,
+                                   void *d_dihedral, void *stream);
+
+/* Which PDQ kernel a context uses for 512x512 RGB8: 0 = generic multi-pass
+ * (any geometry), 1 = fused single-pass (default for 512x512x3).  Debug/bench. */
+int rph_pdq_set_kernel(rph_ctx *ctx, int which);
+
+/* calculate_target_dimensions (pdqhash.rs:224-235): integer geometry, host. */
+void rph_pdq_target_dimensions(uint32_t w, uint32_t h, uint32_t max_dim, uint32_t *new_w, uint32_t *new_h);
+
+/* =====================================================================
+ * Hamming distance, all-pairs sweep, grouping  (reference: src/hamminghash.rs,
+ * src/scanner.rs:1588-1823)
+ * ===================================================================== */
+
+/* HammingHash::hamming_distance for [u8;32] (hamminghash.rs:56-58) and u64 (:34-36);
+ * HammingHash::get_chunk (:29-31, :50-53).  Scalar integer helpers, host. */
+uint32_t rph_hamming_distance256(const uint8_t *a32, const uint8_t *b32);
+uint32_t rph_hamming_distance64(uint64_t a, uint64_t b);
+uint16_t rph_get_chunk256(const uint8_t *h32, uint32_t chunk_idx);
+uint16_t rph_get_chunk64(uint64_t h, uint32_t chunk_idx);
+
+/* One reported pair of the all-pairs sweep. */
+typedef struct rph_edge {
+    uint32_t i, j;  /* i < j (indices into the hash array; for variant sweeps i is the owning file) */
+    uint16_t d;     /* Hamming distance, <= threshold */
+    uint16_t flags; /* RPH_EDGE_* */
+} rph_edge;
+#define RPH_EDGE_MIH_R1 0x8000u      /* pair is reachable by find_groups' R<=1 probing (hamminghash.rs:206-238) */
+#define RPH_EDGE_PROBE_MASK 0x01FFu  /* (first chunk k << 5) | probe slot: 0 = exact bucket, 1+b = flip of bit b */
+#define RPH_EDGE_VARIANT_SHIFT 9     /* variant sweeps: bits 9..11 = dihedral slot that matched */
+#define RPH_EDGE_VARIANT_MASK 0x0E00u
+
+/*
+ * All-pairs 256-bit sweep: every pair i<j of `hashes32` (n x 32 bytes) with
+ * hamming_distance <= threshold (0..256), the exact counterpart of the
+ * candidate generation of group_files_generic (scanner.rs:1704-1767, exact for
+ * threshold <= 63) and, with RPH_EDGE_MIH_R1, of find_groups (hamminghash.rs:206-238).
+ * Edges are written unordered; *n_edges_out always receives the total found; at
+ * most `cap` are stored (RPH_ERR_CAPACITY if more were found).
+ * part/nparts shard the upper-triangular tile pairs round-robin (multi-GPU:
+ * rank r of N passes part=r, nparts=N; single GPU 0,1).
+ */
+int rph_hamming_all_pairs(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t threshold,
+                          uint32_t part, uint32_t nparts, rph_edge *edges, uint64_t cap,
+                          uint64_t *n_edges_out);
+/* d_count: device uint64 cursor, zeroed by the caller before the first shard. */
+int rph_hamming_all_pairs_dev(rph_ctx *ctx, const void *d_hashes32, uint64_t n, uint32_t threshold,
+                              uint32_t part, uint32_t nparts, void *d_edges, uint64_t cap,
+                              void *d_count, void *stream);
+
+/*
+ * Variant sweep of group_files_generic + PdqStrategy (scanner.rs:1607-1637,
+ * 1678-1776): rows are the 8 dihedral hashes of every file (n x 8 x 32 bytes,
+ * or n x 1 x 32 when n_variants == 1), columns the plain hashes; an edge
+ * (i, j, d, variant) is reported for every variant v of file i and every j > i
+ * with hamming_distance(variant_v(i), hash(j)) <= limit(i, j), where
+ * limit = 0 if low_conf[i] or low_conf[j] (scanner.rs:1699,1721) else `similarity`.
+ * low_conf nullable (all 0).  The multiset of (i, j) equals the reference's edge
+ * list (its comparison_count, scanner.rs:1778).
+ */
+int rph_hamming_variant_pairs(rph_ctx *ctx, const uint8_t *variants, uint32_t n_variants,
+                              const uint8_t *hashes32, const uint8_t *low_conf, uint64_t n,
+                              uint32_t similarity, uint32_t part, uint32_t nparts, rph_edge *edges,
+                              uint64_t cap, uint64_t *n_edges_out);
+int rph_hamming_variant_pairs_dev(rph_ctx *ctx, const void *d_variants, uint32_t n_variants,
+                                  const void *d_hashes32, const void *d_low_conf, uint64_t n,
+                                  uint32_t similarity, uint32_t part, uint32_t nparts, void *d_edges,
+                                  uint64_t cap, void *d_count, void *stream);
+
+/*
+ * find_groups::<[u8;32]> (hamminghash.rs:191-271), bit-exact including member
+ * order: adjacency = pairs with d <= max_dist that R<=1 probing reaches, in
+ * first-seen order, then the serial greedy star clustering.
+ * members: capacity n; offsets: capacity n/2 + 2; group g = members[offsets[g] .. offsets[g+1]).
+ */
+int rph_find_groups256(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t max_dist,
+                       uint32_t *members, uint32_t *offsets, uint32_t *n_groups_out);
+/* Same from a precomputed edge list (e.g. gathered from several GPUs). */
+int rph_find_groups_from_edges(const rph_edge *edges, uint64_t n_edges, uint64_t n,
+                               uint32_t *members, uint32_t *offsets, uint32_t *n_groups_out);
+
+/*
+ * group_files_generic with PdqStrategy (scanner.rs:1640-1823) up to and
+ * including the union-find (merge_groups_by_stem / process_raw_groups are
+ * file-name logic and stay in the caller).
+ *   hashes32 n x 32; coeffs n x 256 floats or NULL (then every file has the one
+ *   variant out[0] = hash, scanner.rs:1624-1627); has_features n bytes or NULL
+ *   (all 1 when coeffs != NULL); quality n x int32, <0 = None (scanner.rs:1592), or NULL.
+ * similarity must be <= RPH_MAX_SIMILARITY_256 (scanner.rs:1650-1655) else RPH_ERR_INVALID_ARG.
+ * Outputs: connected components with > 1 member: members ascending inside a
+ * group (scanner.rs:1810-1814), groups ordered by first member (the reference's
+ * HashMap order is unspecified); *comparison_count_out = number of edges
+ * (scanner.rs:1778).  members capacity n, offsets capacity n/2 + 2.
+ */
+int rph_group_files_pdq(rph_ctx *ctx, const uint8_t *hashes32, const float *coeffs,
+                        const uint8_t *has_features, const int32_t *quality, uint64_t n,
+                        uint32_t similarity, uint32_t *members, uint32_t *offsets,
+                        uint32_t *n_groups_out, uint64_t *comparison_count_out);
+/* Union-find part alone (scanner.rs:1781-1817) over an edge list. */
+int rph_union_find_groups(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members,
+                          uint32_t *offsets, uint32_t *n_groups_out);
+
+/* is_low_pdq_quality (scanner.rs:1592-1594); quality < 0 encodes None. */
+int rph_is_low_pdq_quality(int32_t quality);
+
+/* MIHIndex::new (hamminghash.rs:89-130) for [u8;32]: CSR arrays built on the
+ * device.  offsets: 16*65536+1 u32, values: 16*n u32 (ascending id per bucket). */
+int rph_mih_build256(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t *offsets, uint32_t *values);
+
+/* =====================================================================
+ * 64-bit pHash bit operations (reference: src/phash.rs:137-255), host scalar
+ * ===================================================================== */
+uint64_t rph_phash_rotate_90(uint64_t hash);            /* phash.rs:150 */
+uint64_t rph_phash_rotate_180(uint64_t hash);           /* phash.rs:175 */
+uint64_t rph_phash_rotate_270(uint64_t hash);           /* phash.rs:191 */
+uint64_t rph_phash_flip_horizontal(uint64_t hash);      /* phash.rs:220 */
+uint64_t rph_phash_rotation_invariant(uint64_t hash);   /* phash.rs:137 */
+void rph_phash_dihedral(uint64_t hash, uint64_t out8[8]); /* phash.rs:242 */
+
+/* =====================================================================
+ * Synthetic workloads, generated on the device
+ * ===================================================================== */
+/* n RGB8 images w x h, global indices first_k.., packed (row stride 3*w). */
+int rph_synth_images_dev(rph_ctx *ctx, void *d_out, uint64_t first_k, uint32_t n, uint32_t w, uint32_t h,
+                         uint32_t seed, void *stream);
+/* hashes [first, first+count) of a synthetic set of n_total (with n_clusters
+ * injected 5-member clusters and one distance-32 "2 bits per chunk" pair). */
+int rph_synth_hashes_dev(rph_ctx *ctx, void *d_out, uint64_t first, uint64_t count, uint64_t n_total,
+                         uint64_t seed, uint64_t n_clusters, void *stream);
+
+/* Device memory helpers for callers without a HIP binding (tests, bench). */
+int rph_dev_alloc(rph_ctx *ctx, size_t bytes, void **d_ptr_out);
+int rph_dev_free(rph_ctx *ctx, void *d_ptr);
+int rph_dev_upload(rph_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int rph_dev_download(rph_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int rph_dev_memset(rph_ctx *ctx, void *d_dst, int value, size_t bytes, void *stream);
+
+/* Timing hooks used by bench.py: HIP events recorded on `stream` (NULL = the
+ * context's stream), so the measured interval is the kernels' own stream time. */
+int rph_event_create(rph_ctx *ctx, void **event_out);
+int rph_event_record(rph_ctx *ctx, void *event, void *stream);
+int rph_event_elapsed_ms(rph_ctx *ctx, void *start, void *stop, float *ms_out); /* synchronises on stop */
+int rph_event_destroy(rph_ctx *ctx, void *event);
+/* The context's own stream (hipStream_t as void*). */
+void *rph_stream(rph_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUPPHASH_H */

@@ -1,0 +1,117 @@
+"""ctypes binding of librupphash_hip.so (include/rupphash.h).
+
+The library is the product: if it is missing or cannot be loaded, importing a
+function from here raises -- there is no Python or CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librupphash_hip.so")
+
+RPH_OK = 0
+RPH_ERR_INVALID_ARG = -1
+RPH_ERR_NO_DEVICE = -2
+RPH_ERR_HIP = -3
+RPH_ERR_OOM = -4
+RPH_ERR_UNSUPPORTED = -5
+RPH_ERR_CAPACITY = -6
+
+RPH_EDGE_MIH_R1 = 0x8000
+RPH_EDGE_PROBE_MASK = 0x01FF
+RPH_EDGE_VARIANT_SHIFT = 9
+RPH_EDGE_VARIANT_MASK = 0x0E00
+
+
+class RphEdge(C.Structure):
+    _fields_ = [("i", C.c_uint32), ("j", C.c_uint32), ("d", C.c_uint16), ("flags", C.c_uint16)]
+
+
+class RphError(RuntimeError):
+    def __init__(self, status, where, detail):
+        super().__init__(f"{where}: status {status} ({detail})")
+        self.status = status
+
+
+_vp, _u8p, _f32p, _u32p, _i32p, _u64p = (C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); this table is what tests/test_abi.py checks against include/rupphash.h
+SIGNATURES = {
+    "rph_abi_version": (C.c_int, []),
+    "rph_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "rph_shutdown": (C.c_int, [_vp]),
+    "rph_last_error": (C.c_char_p, []),
+    "rph_status_string": (C.c_char_p, [C.c_int]),
+    "rph_device_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "rph_synchronize": (C.c_int, [_vp]),
+    "rph_pdq_hash_batch": (C.c_int, [_vp, _u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _sz, _sz, _u8p, _f32p,
+                                     _f32p, _u8p, _u8p]),
+    "rph_pdq_hash_batch_dev": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _sz, _sz, _vp, _vp, _vp,
+                                         _vp, _vp, _vp]),
+    "rph_pdq_hashes_from_coeffs": (C.c_int, [_vp, _f32p, C.c_uint32, _u8p, _u8p]),
+    "rph_pdq_hashes_from_coeffs_dev": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "rph_pdq_set_kernel": (C.c_int, [_vp, C.c_int]),
+    "rph_pdq_target_dimensions": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rph_hamming_distance256": (C.c_uint32, [_u8p, _u8p]),
+    "rph_hamming_distance64": (C.c_uint32, [C.c_uint64, C.c_uint64]),
+    "rph_get_chunk256": (C.c_uint16, [_u8p, C.c_uint32]),
+    "rph_get_chunk64": (C.c_uint16, [C.c_uint64, C.c_uint32]),
+    "rph_hamming_all_pairs": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64,
+                                        C.POINTER(C.c_uint64)]),
+    "rph_hamming_all_pairs_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, _vp]),
+    "rph_hamming_variant_pairs": (C.c_int, [_vp, _u8p, C.c_uint32, _u8p, _u8p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                            C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "rph_hamming_variant_pairs_dev": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                C.c_uint32, _vp, C.c_uint64, _vp, _vp]),
+    "rph_find_groups256": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_uint32, _u32p, _u32p, C.POINTER(C.c_uint32)]),
+    "rph_find_groups_from_edges": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u32p, _u32p, C.POINTER(C.c_uint32)]),
+    "rph_group_files_pdq": (C.c_int, [_vp, _u8p, _f32p, _u8p, _i32p, C.c_uint64, C.c_uint32, _u32p, _u32p,
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "rph_union_find_groups": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u32p, _u32p, C.POINTER(C.c_uint32)]),
+    "rph_is_low_pdq_quality": (C.c_int, [C.c_int32]),
+    "rph_mih_build256": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, _u32p]),
+    "rph_phash_rotate_90": (C.c_uint64, [C.c_uint64]),
+    "rph_phash_rotate_180": (C.c_uint64, [C.c_uint64]),
+    "rph_phash_rotate_270": (C.c_uint64, [C.c_uint64]),
+    "rph_phash_flip_horizontal": (C.c_uint64, [C.c_uint64]),
+    "rph_phash_rotation_invariant": (C.c_uint64, [C.c_uint64]),
+    "rph_phash_dihedral": (None, [C.c_uint64, _u64p]),
+    "rph_synth_images_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
+    "rph_synth_hashes_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
+    "rph_dev_alloc": (C.c_int, [_vp, _sz, C.POINTER(C.c_void_p)]),
+    "rph_dev_free": (C.c_int, [_vp, _vp]),
+    "rph_dev_upload": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "rph_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "rph_dev_memset": (C.c_int, [_vp, _vp, C.c_int, _sz, _vp]),
+    "rph_event_create": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "rph_event_record": (C.c_int, [_vp, _vp, _vp]),
+    "rph_event_elapsed_ms": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
+    "rph_event_destroy": (C.c_int, [_vp, _vp]),
+    "rph_stream": (C.c_void_p, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librupphash_hip.so (built by `make -C rupphash_amd/csrc` or __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C rupphash_amd/csrc` (hipcc, --offload-arch=gfx950). "
+                "rupphash_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the library does not export what the header declares
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, where):
+    if status != RPH_OK:
+        L = load()
+        raise RphError(status, where, (L.rph_last_error() or b"").decode() or L.rph_status_string(status).decode())

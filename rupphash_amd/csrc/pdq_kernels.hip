@@ -1,0 +1,182 @@
+// pdq_kernels.hip -- PDQ hashing kernels for gfx950 (generic multi-pass path + hashes from coefficients).
+//
+// Replaces /root/reference/src/pdqhash.rs:238-262 (generate_pdq_from_luma) and :59-87
+// (to_hash, generate_dihedral_hashes) for batches of equally sized images.
+//
+// Generic path (any w, h in 5..512; 1/3/4 channels): f32 planes in HBM scratch,
+//   luma -> [box rows -> box cols] x 2 -> decimate + tail (one wave per image).
+// Every 1-D box line is walked by ONE thread in the reference's exact order
+// (sum += in[ri]; sum -= in[li]; out = sum / cur_win), so it is bit-exact by construction.
+// It is the correctness baseline and the path for odd geometries; 512x512 RGB8 goes
+// through the fused single-pass kernel in pdq_fused512.hip.
+#include "pdq_tail.hpp"
+#include "rph_internal.h"
+
+namespace {
+
+// ---- to_luma601 (pdqhash.rs:268-284) + u8 -> f32 (:244) ----
+__global__ void __launch_bounds__(256) luma_kernel(const uint8_t *__restrict__ px, uint32_t n, uint32_t w, uint32_t h,
+                                                   uint32_t channels, size_t row_stride, size_t image_stride,
+                                                   float *__restrict__ plane)
+{
+    const uint64_t total = (uint64_t)n * w * h;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t img = (uint32_t)(t / ((uint64_t)w * h));
+        const uint32_t rem = (uint32_t)(t - (uint64_t)img * w * h);
+        const uint32_t y = rem / w, x = rem - y * w;
+        const uint8_t *p = px + (size_t)img * image_stride + (size_t)y * row_stride + (size_t)x * channels;
+        uint32_t v;
+        if (channels == 1)
+            v = p[0];
+        else
+            v = (299u * p[0] + 587u * p[1] + 114u * p[2] + 500u) / 1000u;
+        plane[t] = (float)v;
+    }
+}
+
+// ---- box_one_d_float (pdqhash.rs:341-396), one line per thread ----
+__device__ __forceinline__ void box_one_d(const float *__restrict__ in, float *__restrict__ out, uint32_t len,
+                                          size_t stride, uint32_t win)
+{
+    const uint32_t maxlen = len > 1 ? len : 1;
+    win = win < 1 ? 1 : (win > maxlen ? maxlen : win);
+    const uint32_t half = (win + 2) / 2;
+    const uint32_t phase_1 = half - 1, phase_2 = win - half + 1, phase_3 = len > win ? len - win : 0, phase_4 = half - 1;
+    size_t li = 0, ri = 0, oi = 0;
+    float sum = 0.0f, cur = 0.0f;
+    for (uint32_t t = 0; t < phase_1; t++) {
+        sum = sum + in[ri];
+        cur = cur + 1.0f;
+        ri += stride;
+    }
+    for (uint32_t t = 0; t < phase_2; t++) {
+        sum = sum + in[ri];
+        cur = cur + 1.0f;
+        out[oi] = sum / cur;
+        ri += stride;
+        oi += stride;
+    }
+    for (uint32_t t = 0; t < phase_3; t++) {
+        sum = sum + in[ri];
+        sum = sum - in[li];
+        out[oi] = sum / cur;
+        li += stride;
+        ri += stride;
+        oi += stride;
+    }
+    for (uint32_t t = 0; t < phase_4; t++) {
+        sum = sum - in[li];
+        cur = cur - 1.0f;
+        out[oi] = sum / cur;
+        li += stride;
+        oi += stride;
+    }
+}
+
+// box_along_rows_float (pdqhash.rs:398-402): thread = (image, row)
+__global__ void __launch_bounds__(64) box_rows_kernel(const float *__restrict__ in, float *__restrict__ out, uint32_t n,
+                                                      uint32_t h, uint32_t w, uint32_t win)
+{
+    const uint64_t line = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (line >= (uint64_t)n * h) return;
+    box_one_d(in + line * w, out + line * w, w, 1, win);
+}
+
+// box_along_cols_float (pdqhash.rs:404-408): thread = (image, column)
+__global__ void __launch_bounds__(64) box_cols_kernel(const float *__restrict__ in, float *__restrict__ out, uint32_t n,
+                                                      uint32_t h, uint32_t w, uint32_t win)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n * w) return;
+    const uint32_t img = (uint32_t)(t / w), col = (uint32_t)(t - (uint64_t)img * w);
+    const size_t base = (size_t)img * h * w + col;
+    box_one_d(in + base, out + base, h, w, win);
+}
+
+// decimate_float::<64,64> (pdqhash.rs:428-443) + tail; one wave per image
+__global__ void __launch_bounds__(64) tail_generic_kernel(const float *__restrict__ plane, uint32_t n, uint32_t h, uint32_t w,
+                                                          uint8_t *hash, float *quality, float *coeffs, uint8_t *dihedral)
+{
+    __shared__ float lds[rph::TAIL_LDS_FLOATS];
+    const uint32_t img = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float *p = plane + (size_t)img * h * w;
+    const uint32_t cj = ((uint32_t)(lane * 2 + 1) * w) / 128u;
+    float b[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        const uint32_t ri = ((uint32_t)(i * 2 + 1) * h) / 128u;
+        b[i] = p[(size_t)ri * w + cj];
+    }
+    rph::pdq_tail(b, lds, lane, hash ? hash + (size_t)img * 32 : nullptr, quality ? quality + img : nullptr,
+                  coeffs ? coeffs + (size_t)img * 256 : nullptr, dihedral ? dihedral + (size_t)img * 256 : nullptr);
+}
+
+// PdqFeatures::to_hash / generate_dihedral_hashes for stored coefficients; one wave per image
+__global__ void __launch_bounds__(64) from_coeffs_kernel(const float *__restrict__ coeffs, uint32_t n, uint8_t *hash,
+                                                         uint8_t *dihedral)
+{
+    __shared__ float lds_c[256];
+    const uint32_t img = blockIdx.x;
+    const int lane = threadIdx.x;
+    float c[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) c[m] = coeffs[(size_t)img * 256 + lane + 64 * m];
+    rph::hashes_from_coeffs(c, lds_c, lane, hash ? hash + (size_t)img * 32 : nullptr,
+                            dihedral ? dihedral + (size_t)img * 256 : nullptr);
+}
+
+}  // namespace
+
+int rph_launch_pdq_from_coeffs(const float *d_coeffs, uint32_t n, uint8_t *d_hash, uint8_t *d_dihedral, hipStream_t stream)
+{
+    if (n == 0) return RPH_OK;
+    hipLaunchKernelGGL(from_coeffs_kernel, dim3(n), dim3(64), 0, stream, d_coeffs, n, d_hash, d_dihedral);
+    RPH_HIP_CHECK(hipGetLastError());
+    return RPH_OK;
+}
+
+int rph_launch_pdq_generic(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels,
+                           size_t row_stride, size_t image_stride, uint8_t *d_hash, float *d_quality, float *d_coeffs,
+                           uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream)
+{
+    if (n == 0) return RPH_OK;
+    if (d_valid) RPH_HIP_CHECK(hipMemsetAsync(d_valid, 1, n, stream));
+    const size_t plane_bytes = (size_t)w * h * sizeof(float);
+    // two planes per image in flight; cap the scratch at 512 MiB
+    uint32_t chunk = (uint32_t)((size_t)(256u << 20) / plane_bytes);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    const size_t need = 2 * plane_bytes * chunk;
+    if (ctx->scratch_bytes < need) {
+        // the generic path owns its stream order: make sure earlier work using the old scratch is done
+        RPH_HIP_CHECK(hipStreamSynchronize(stream));
+        if (ctx->scratch) RPH_HIP_CHECK(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        RPH_HIP_CHECK(hipMalloc((void **)&ctx->scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    float *a = ctx->scratch, *b = ctx->scratch + (size_t)chunk * w * h;
+    const uint32_t win_rows = (w + 63) / 64;  // window along rows = ceil(cols / 64)   pdqhash.rs:246
+    const uint32_t win_cols = (h + 63) / 64;  // window along cols = ceil(rows / 64)   pdqhash.rs:247
+    for (uint32_t first = 0; first < n; first += chunk) {
+        const uint32_t m = (n - first) < chunk ? (n - first) : chunk;
+        const uint64_t total = (uint64_t)m * w * h;
+        const uint64_t want = (total + 255) / 256;
+        hipLaunchKernelGGL(luma_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, stream,
+                           d_px + (size_t)first * image_stride, m, w, h, channels, row_stride, image_stride, a);
+        for (int rep = 0; rep < 2; rep++) {  // PDQ_NUM_JAROSZ_XY_PASSES = 2 (pdqhash.rs:18, :422-425)
+            hipLaunchKernelGGL(box_rows_kernel, dim3((unsigned)(((uint64_t)m * h + 63) / 64)), dim3(64), 0, stream, a, b, m, h, w,
+                               win_rows);
+            hipLaunchKernelGGL(box_cols_kernel, dim3((unsigned)(((uint64_t)m * w + 63) / 64)), dim3(64), 0, stream, b, a, m, h, w,
+                               win_cols);
+        }
+        hipLaunchKernelGGL(tail_generic_kernel, dim3(m), dim3(64), 0, stream, a, m, h, w,
+                           d_hash ? d_hash + (size_t)first * 32 : nullptr, d_quality ? d_quality + first : nullptr,
+                           d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr,
+                           d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr);
+        RPH_HIP_CHECK(hipGetLastError());
+    }
+    return RPH_OK;
+}

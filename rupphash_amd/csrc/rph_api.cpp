@@ -1,0 +1,558 @@
+// rph_api.cpp -- extern "C" surface of librupphash_hip.so (see include/rupphash.h).
+// Host-pointer entry points stage through device memory and call the *_dev twins; there is no
+// CPU implementation of any kernel behind this API.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "rph_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void rph_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+// RAII device buffer for the host-pointer wrappers
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes)
+    {
+        RPH_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+        return RPH_OK;
+    }
+    template <class T>
+    T *as() const
+    {
+        return reinterpret_cast<T *>(p);
+    }
+};
+#define RPH_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != RPH_OK) return rc_; \
+    } while (0)
+
+hipStream_t pick(rph_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+}  // namespace
+
+static int sweep_host(rph_ctx *ctx, const uint8_t *variants, uint32_t n_variants, const uint8_t *hashes32,
+                      const uint8_t *low_conf, const uint8_t *has_features, uint64_t n, uint32_t thr, uint32_t part,
+                      uint32_t nparts, rph_edge *edges, uint64_t cap, uint64_t *n_edges_out)
+{
+    if (!ctx || (!hashes32 && n) || !n_edges_out || (!edges && cap)) {
+        rph_set_error("hamming sweep: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    *n_edges_out = 0;
+    if (n < 2) return RPH_OK;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    DevBuf d_h, d_v, d_lc, d_hf, d_e, d_cnt;
+    RPH_TRY(d_h.alloc(n * 32));
+    RPH_HIP_CHECK(hipMemcpyAsync(d_h.p, hashes32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    const uint8_t *rows = (const uint8_t *)d_h.p;
+    if (variants) {
+        RPH_TRY(d_v.alloc(n * 32 * n_variants));
+        RPH_HIP_CHECK(hipMemcpyAsync(d_v.p, variants, n * 32 * n_variants, hipMemcpyHostToDevice, ctx->stream));
+        rows = (const uint8_t *)d_v.p;
+    } else {
+        n_variants = 1;
+    }
+    if (low_conf) {
+        RPH_TRY(d_lc.alloc(n));
+        RPH_HIP_CHECK(hipMemcpyAsync(d_lc.p, low_conf, n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (has_features) {
+        RPH_TRY(d_hf.alloc(n));
+        RPH_HIP_CHECK(hipMemcpyAsync(d_hf.p, has_features, n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    RPH_TRY(d_e.alloc(cap * sizeof(rph_edge)));
+    RPH_TRY(d_cnt.alloc(8));
+    RPH_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, 8, ctx->stream));
+    RPH_TRY(rph_launch_hamming_sweep(rows, n_variants, (const uint8_t *)d_h.p, (const uint8_t *)d_lc.p,
+                                     (const uint8_t *)d_hf.p, n, thr, part, nparts, (rph_edge *)d_e.p, cap,
+                                     (unsigned long long *)d_cnt.p, ctx->stream));
+    unsigned long long cnt = 0;
+    RPH_HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *n_edges_out = cnt;
+    const uint64_t take = std::min<uint64_t>(cnt, cap);
+    if (take) RPH_HIP_CHECK(hipMemcpy(edges, d_e.p, take * sizeof(rph_edge), hipMemcpyDeviceToHost));
+    if (cnt > cap) {
+        rph_set_error("hamming sweep: %llu edges found, capacity %llu", cnt, (unsigned long long)cap);
+        return RPH_ERR_CAPACITY;
+    }
+    return RPH_OK;
+}
+
+// Run a sweep whose edge count is not known in advance: grow the edge buffer until it fits.
+template <class F>
+static int sweep_growing(uint64_t n, std::vector<rph_edge> &edges, F &&run)
+{
+    uint64_t cap = std::max<uint64_t>(1u << 20, 4 * n);
+    for (int attempt = 0; attempt < 8; attempt++) {
+        edges.resize(cap);
+        uint64_t found = 0;
+        int rc = run(edges.data(), cap, &found);
+        if (rc == RPH_OK) {
+            edges.resize(found);
+            return RPH_OK;
+        }
+        if (rc != RPH_ERR_CAPACITY) return rc;
+        cap = found + found / 8 + 1024;
+    }
+    return RPH_ERR_CAPACITY;
+}
+
+extern "C" {
+
+int rph_abi_version(void) { return RPH_ABI_VERSION; }
+const char *rph_last_error(void) { return g_err; }
+const char *rph_status_string(int s)
+{
+    switch (s) {
+        case RPH_OK: return "ok";
+        case RPH_ERR_INVALID_ARG: return "invalid argument";
+        case RPH_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case RPH_ERR_HIP: return "HIP runtime error";
+        case RPH_ERR_OOM: return "out of device memory";
+        case RPH_ERR_UNSUPPORTED: return "unsupported input";
+        case RPH_ERR_CAPACITY: return "output capacity too small";
+    }
+    return "unknown status";
+}
+
+int rph_init(int device, rph_ctx **out)
+{
+    if (!out) return RPH_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        rph_set_error("rph_init: no HIP device visible (this library has no CPU fallback)");
+        return RPH_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        rph_set_error("rph_init: device %d out of range (%d visible)", device, count);
+        return RPH_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    RPH_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        rph_set_error("rph_init: device %d is %s; this build targets gfx950 (MI355X) only", device, prop.gcnArchName);
+        return RPH_ERR_NO_DEVICE;
+    }
+    RPH_HIP_CHECK(hipSetDevice(device));
+    rph_ctx *ctx = new rph_ctx();
+    ctx->device = device;
+    ctx->compute_units = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        rph_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return RPH_ERR_HIP;
+    }
+    *out = ctx;
+    return RPH_OK;
+}
+
+int rph_shutdown(rph_ctx *ctx)
+{
+    if (!ctx) return RPH_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RPH_OK;
+}
+
+int rph_device_info(rph_ctx *ctx, char *name64, int *cus, uint64_t *total_mem)
+{
+    if (!ctx) return RPH_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    RPH_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+    if (name64) snprintf(name64, 64, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cus) *cus = prop.multiProcessorCount;
+    if (total_mem) *total_mem = prop.totalGlobalMem;
+    return RPH_OK;
+}
+
+int rph_synchronize(rph_ctx *ctx)
+{
+    if (!ctx) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RPH_OK;
+}
+
+void *rph_stream(rph_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int rph_pdq_set_kernel(rph_ctx *ctx, int which)
+{
+    if (!ctx || which < 0 || which > 1) return RPH_ERR_INVALID_ARG;
+    ctx->pdq_kernel = which;
+    return RPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// PDQ
+// ------------------------------------------------------------------------------------------
+int rph_pdq_hash_batch_dev(rph_ctx *ctx, const void *d_px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels,
+                           size_t row_stride, size_t image_stride, void *d_hash32, void *d_quality, void *d_coeffs,
+                           void *d_dihedral, void *d_valid, void *stream)
+{
+    if (!ctx || (!d_px && n) || !d_hash32 || (channels != 1 && channels != 3 && channels != 4) ||
+        row_stride < (size_t)w * channels || image_stride < row_stride * (h ? h - 1 : 0) + (size_t)w * channels) {
+        rph_set_error("rph_pdq_hash_batch: invalid argument (n=%u %ux%ux%u row_stride=%zu image_stride=%zu)", n, w, h,
+                      channels, row_stride, image_stride);
+        return RPH_ERR_INVALID_ARG;
+    }
+    if (n == 0) return RPH_OK;
+    hipStream_t s = pick(ctx, stream);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    if (w < RPH_PDQ_MIN_DIM || h < RPH_PDQ_MIN_DIM) {
+        // generate_pdq_features returns None (pdqhash.rs:167-169): valid = 0, outputs zeroed
+        RPH_HIP_CHECK(hipMemsetAsync(d_hash32, 0, (size_t)n * 32, s));
+        if (d_quality) RPH_HIP_CHECK(hipMemsetAsync(d_quality, 0, (size_t)n * 4, s));
+        if (d_coeffs) RPH_HIP_CHECK(hipMemsetAsync(d_coeffs, 0, (size_t)n * 1024, s));
+        if (d_dihedral) RPH_HIP_CHECK(hipMemsetAsync(d_dihedral, 0, (size_t)n * 256, s));
+        if (d_valid) RPH_HIP_CHECK(hipMemsetAsync(d_valid, 0, n, s));
+        return RPH_OK;
+    }
+    if (w > RPH_PDQ_MAX_DIM || h > RPH_PDQ_MAX_DIM) {
+        rph_set_error("rph_pdq_hash_batch: %ux%u needs the reference's >512 px pre-downsample "
+                      "(fast_image_resize, pdqhash.rs:181-220), which is not built yet",
+                      w, h);
+        return RPH_ERR_UNSUPPORTED;
+    }
+    if (ctx->pdq_kernel == 1 && w == 512 && h == 512 && channels == 3 && (row_stride % 4) == 0 && (image_stride % 4) == 0 &&
+        ((uintptr_t)d_px % 4) == 0) {
+        int rc = rph_launch_pdq_fused512(ctx, (const uint8_t *)d_px, n, row_stride, image_stride, (uint8_t *)d_hash32,
+                                         (float *)d_quality, (float *)d_coeffs, (uint8_t *)d_dihedral, (uint8_t *)d_valid, s);
+        if (rc != RPH_ERR_UNSUPPORTED) return rc;
+    }
+    return rph_launch_pdq_generic(ctx, (const uint8_t *)d_px, n, w, h, channels, row_stride, image_stride, (uint8_t *)d_hash32,
+                                  (float *)d_quality, (float *)d_coeffs, (uint8_t *)d_dihedral, (uint8_t *)d_valid, s);
+}
+
+int rph_pdq_hash_batch(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels,
+                       size_t row_stride, size_t image_stride, uint8_t *hash32_out, float *quality_out, float *coeffs_out,
+                       uint8_t *dihedral_out, uint8_t *valid_out)
+{
+    if (!ctx || (!px && n) || !hash32_out) {
+        rph_set_error("rph_pdq_hash_batch: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    if (n == 0) return RPH_OK;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    // stage in chunks of <= 1 GiB of pixels
+    const size_t per = image_stride ? image_stride : 1;
+    uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / per);
+    chunk = std::min(chunk, n);
+    DevBuf d_px, d_hash, d_q, d_c, d_d, d_v;
+    RPH_TRY(d_px.alloc(per * chunk));
+    RPH_TRY(d_hash.alloc((size_t)chunk * 32));
+    if (quality_out) RPH_TRY(d_q.alloc((size_t)chunk * 4));
+    if (coeffs_out) RPH_TRY(d_c.alloc((size_t)chunk * 1024));
+    if (dihedral_out) RPH_TRY(d_d.alloc((size_t)chunk * 256));
+    if (valid_out) RPH_TRY(d_v.alloc(chunk));
+    for (uint32_t first = 0; first < n; first += chunk) {
+        const uint32_t m = std::min(chunk, n - first);
+        // the last image may be shorter than image_stride in the caller's buffer
+        const size_t last_bytes = (size_t)(h ? h - 1 : 0) * row_stride + (size_t)w * channels;
+        const size_t bytes = (size_t)(m - 1) * per + last_bytes;
+        RPH_HIP_CHECK(hipMemcpyAsync(d_px.p, px + (size_t)first * per, bytes, hipMemcpyHostToDevice, ctx->stream));
+        RPH_TRY(rph_pdq_hash_batch_dev(ctx, d_px.p, m, w, h, channels, row_stride, image_stride, d_hash.p, d_q.p, d_c.p,
+                                       d_d.p, d_v.p, ctx->stream));
+        RPH_HIP_CHECK(hipMemcpyAsync(hash32_out + (size_t)first * 32, d_hash.p, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (quality_out) RPH_HIP_CHECK(hipMemcpyAsync(quality_out + first, d_q.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (coeffs_out)
+            RPH_HIP_CHECK(hipMemcpyAsync(coeffs_out + (size_t)first * 256, d_c.p, (size_t)m * 1024, hipMemcpyDeviceToHost, ctx->stream));
+        if (dihedral_out)
+            RPH_HIP_CHECK(hipMemcpyAsync(dihedral_out + (size_t)first * 256, d_d.p, (size_t)m * 256, hipMemcpyDeviceToHost, ctx->stream));
+        if (valid_out) RPH_HIP_CHECK(hipMemcpyAsync(valid_out + first, d_v.p, m, hipMemcpyDeviceToHost, ctx->stream));
+        RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return RPH_OK;
+}
+
+int rph_pdq_hashes_from_coeffs_dev(rph_ctx *ctx, const void *d_coeffs, uint32_t n, void *d_hash32, void *d_dihedral,
+                                   void *stream)
+{
+    if (!ctx || (!d_coeffs && n) || (!d_hash32 && !d_dihedral)) {
+        rph_set_error("rph_pdq_hashes_from_coeffs: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    return rph_launch_pdq_from_coeffs((const float *)d_coeffs, n, (uint8_t *)d_hash32, (uint8_t *)d_dihedral, pick(ctx, stream));
+}
+
+int rph_pdq_hashes_from_coeffs(rph_ctx *ctx, const float *coeffs, uint32_t n, uint8_t *hash32_out, uint8_t *dihedral_out)
+{
+    if (!ctx || (!coeffs && n) || (!hash32_out && !dihedral_out)) {
+        rph_set_error("rph_pdq_hashes_from_coeffs: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    if (n == 0) return RPH_OK;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    DevBuf d_c, d_h, d_d;
+    RPH_TRY(d_c.alloc((size_t)n * 1024));
+    if (hash32_out) RPH_TRY(d_h.alloc((size_t)n * 32));
+    if (dihedral_out) RPH_TRY(d_d.alloc((size_t)n * 256));
+    RPH_HIP_CHECK(hipMemcpyAsync(d_c.p, coeffs, (size_t)n * 1024, hipMemcpyHostToDevice, ctx->stream));
+    RPH_TRY(rph_pdq_hashes_from_coeffs_dev(ctx, d_c.p, n, d_h.p, d_d.p, ctx->stream));
+    if (hash32_out) RPH_HIP_CHECK(hipMemcpyAsync(hash32_out, d_h.p, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (dihedral_out) RPH_HIP_CHECK(hipMemcpyAsync(dihedral_out, d_d.p, (size_t)n * 256, hipMemcpyDeviceToHost, ctx->stream));
+    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Hamming
+// ------------------------------------------------------------------------------------------
+int rph_hamming_all_pairs_dev(rph_ctx *ctx, const void *d_hashes32, uint64_t n, uint32_t threshold, uint32_t part,
+                              uint32_t nparts, void *d_edges, uint64_t cap, void *d_count, void *stream)
+{
+    if (!ctx || (!d_hashes32 && n) || !d_count || (!d_edges && cap)) {
+        rph_set_error("rph_hamming_all_pairs: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    return rph_launch_hamming_sweep((const uint8_t *)d_hashes32, 1, (const uint8_t *)d_hashes32, nullptr, nullptr, n, threshold,
+                                    part, nparts, (rph_edge *)d_edges, cap, (unsigned long long *)d_count, pick(ctx, stream));
+}
+
+int rph_hamming_variant_pairs_dev(rph_ctx *ctx, const void *d_variants, uint32_t n_variants, const void *d_hashes32,
+                                  const void *d_low_conf, uint64_t n, uint32_t similarity, uint32_t part, uint32_t nparts,
+                                  void *d_edges, uint64_t cap, void *d_count, void *stream)
+{
+    if (!ctx || ((!d_variants || !d_hashes32) && n) || !d_count || (!d_edges && cap)) {
+        rph_set_error("rph_hamming_variant_pairs: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    return rph_launch_hamming_sweep((const uint8_t *)d_variants, n_variants, (const uint8_t *)d_hashes32,
+                                    (const uint8_t *)d_low_conf, nullptr, n, similarity, part, nparts, (rph_edge *)d_edges, cap,
+                                    (unsigned long long *)d_count, pick(ctx, stream));
+}
+
+int rph_hamming_all_pairs(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t threshold, uint32_t part,
+                          uint32_t nparts, rph_edge *edges, uint64_t cap, uint64_t *n_edges_out)
+{
+    return sweep_host(ctx, nullptr, 1, hashes32, nullptr, nullptr, n, threshold, part, nparts, edges, cap, n_edges_out);
+}
+
+int rph_hamming_variant_pairs(rph_ctx *ctx, const uint8_t *variants, uint32_t n_variants, const uint8_t *hashes32,
+                              const uint8_t *low_conf, uint64_t n, uint32_t similarity, uint32_t part, uint32_t nparts,
+                              rph_edge *edges, uint64_t cap, uint64_t *n_edges_out)
+{
+    if (!variants && n) {
+        rph_set_error("rph_hamming_variant_pairs: variants is null");
+        return RPH_ERR_INVALID_ARG;
+    }
+    return sweep_host(ctx, variants, n_variants, hashes32, low_conf, nullptr, n, similarity, part, nparts, edges, cap,
+                      n_edges_out);
+}
+
+int rph_find_groups_from_edges(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,
+                               uint32_t *n_groups_out)
+{
+    if ((!edges && n_edges) || !members || !offsets || !n_groups_out) return RPH_ERR_INVALID_ARG;
+    return rph_host_find_groups(edges, n_edges, n, members, offsets, n_groups_out);
+}
+
+int rph_union_find_groups(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,
+                          uint32_t *n_groups_out)
+{
+    if ((!edges && n_edges) || !members || !offsets || !n_groups_out) return RPH_ERR_INVALID_ARG;
+    return rph_host_union_find(edges, n_edges, n, members, offsets, n_groups_out);
+}
+
+int rph_find_groups256(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t max_dist, uint32_t *members,
+                       uint32_t *offsets, uint32_t *n_groups_out)
+{
+    if (!ctx || (!hashes32 && n) || !members || !offsets || !n_groups_out) {
+        rph_set_error("rph_find_groups256: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    *n_groups_out = 0;
+    offsets[0] = 0;
+    if (n < 2) return RPH_OK;
+    std::vector<rph_edge> edges;
+    RPH_TRY(sweep_growing(n, edges, [&](rph_edge *e, uint64_t cap, uint64_t *found) {
+        return sweep_host(ctx, nullptr, 1, hashes32, nullptr, nullptr, n, max_dist, 0, 1, e, cap, found);
+    }));
+    return rph_host_find_groups(edges.data(), edges.size(), n, members, offsets, n_groups_out);
+}
+
+int rph_group_files_pdq(rph_ctx *ctx, const uint8_t *hashes32, const float *coeffs, const uint8_t *has_features,
+                        const int32_t *quality, uint64_t n, uint32_t similarity, uint32_t *members, uint32_t *offsets,
+                        uint32_t *n_groups_out, uint64_t *comparison_count_out)
+{
+    if (!ctx || (!hashes32 && n) || !members || !offsets || !n_groups_out) {
+        rph_set_error("rph_group_files_pdq: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    if (similarity > RPH_MAX_SIMILARITY_256) {
+        // scanner.rs:1650-1655 asserts this
+        rph_set_error("Similarity distances above %u require R=4 bit-flip checks, which are not implemented.",
+                      RPH_MAX_SIMILARITY_256);
+        return RPH_ERR_INVALID_ARG;
+    }
+    *n_groups_out = 0;
+    offsets[0] = 0;
+    if (comparison_count_out) *comparison_count_out = 0;
+    if (n < 2) return RPH_OK;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+
+    std::vector<uint8_t> low_conf;
+    if (quality) {
+        low_conf.resize(n);
+        for (uint64_t i = 0; i < n; i++) low_conf[i] = (uint8_t)rph_is_low_pdq_quality(quality[i]);
+    }
+    // 8 dihedral variants per file from its coefficients (scanner.rs:1621-1623); files without
+    // features contribute their hash as the only variant (:1624-1627)
+    std::vector<uint8_t> variants;
+    if (coeffs) {
+        variants.resize(n * 256);
+        const uint32_t step = 1u << 20;
+        for (uint64_t first = 0; first < n; first += step) {
+            const uint32_t m = (uint32_t)std::min<uint64_t>(step, n - first);
+            RPH_TRY(rph_pdq_hashes_from_coeffs(ctx, coeffs + first * 256, m, nullptr, variants.data() + first * 256));
+        }
+        if (has_features)
+            for (uint64_t i = 0; i < n; i++)
+                if (!has_features[i])
+                    for (int v = 0; v < 8; v++) std::memcpy(&variants[i * 256 + v * 32], hashes32 + i * 32, 32);
+    }
+    std::vector<rph_edge> edges;
+    RPH_TRY(sweep_growing(n, edges, [&](rph_edge *e, uint64_t cap, uint64_t *found) {
+        return sweep_host(ctx, coeffs ? variants.data() : nullptr, coeffs ? 8 : 1, hashes32,
+                          quality ? low_conf.data() : nullptr, (coeffs && has_features) ? has_features : nullptr, n, similarity,
+                          0, 1, e, cap, found);
+    }));
+    if (comparison_count_out) *comparison_count_out = edges.size();
+    return rph_host_union_find(edges.data(), edges.size(), n, members, offsets, n_groups_out);
+}
+
+int rph_mih_build256(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t *offsets, uint32_t *values)
+{
+    if (!ctx || (!hashes32 && n) || !offsets || (!values && n)) {
+        rph_set_error("rph_mih_build256: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t n_off = (size_t)16 * 65536 + 1;
+    DevBuf d_h, d_o, d_v;
+    RPH_TRY(d_h.alloc(n * 32));
+    RPH_TRY(d_o.alloc(n_off * 4));
+    RPH_TRY(d_v.alloc(n * 16 * 4));
+    RPH_HIP_CHECK(hipMemcpyAsync(d_h.p, hashes32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        RPH_TRY(rph_launch_mih_build256(ctx, (const uint8_t *)d_h.p, n, (uint32_t *)d_o.p, (uint32_t *)d_v.p, ctx->stream));
+    }
+    RPH_HIP_CHECK(hipMemcpyAsync(offsets, d_o.p, n_off * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (n) RPH_HIP_CHECK(hipMemcpyAsync(values, d_v.p, n * 16 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic workloads, device memory helpers, events
+// ------------------------------------------------------------------------------------------
+int rph_synth_images_dev(rph_ctx *ctx, void *d_out, uint64_t first_k, uint32_t n, uint32_t w, uint32_t h, uint32_t seed,
+                         void *stream)
+{
+    if (!ctx || (!d_out && n)) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    return rph_launch_synth_images((uint8_t *)d_out, first_k, n, w, h, seed, pick(ctx, stream));
+}
+
+int rph_synth_hashes_dev(rph_ctx *ctx, void *d_out, uint64_t first, uint64_t count, uint64_t n_total, uint64_t seed,
+                         uint64_t n_clusters, void *stream)
+{
+    if (!ctx || (!d_out && count)) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    return rph_launch_synth_hashes((uint8_t *)d_out, first, count, n_total, seed, n_clusters, pick(ctx, stream));
+}
+
+int rph_dev_alloc(rph_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    RPH_HIP_CHECK(hipMalloc(out, bytes ? bytes : 1));
+    return RPH_OK;
+}
+int rph_dev_free(rph_ctx *ctx, void *p)
+{
+    if (!ctx) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    if (p) RPH_HIP_CHECK(hipFree(p));
+    return RPH_OK;
+}
+int rph_dev_upload(rph_ctx *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (!ctx || ((!d_dst || !src) && bytes)) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    RPH_HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RPH_OK;
+}
+int rph_dev_download(rph_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (!ctx || ((!dst || !d_src) && bytes)) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    RPH_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RPH_OK;
+}
+int rph_dev_memset(rph_ctx *ctx, void *d_dst, int value, size_t bytes, void *stream)
+{
+    if (!ctx || (!d_dst && bytes)) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    RPH_HIP_CHECK(hipMemsetAsync(d_dst, value, bytes, pick(ctx, stream)));
+    return RPH_OK;
+}
+
+int rph_event_create(rph_ctx *ctx, void **event_out)
+{
+    if (!ctx || !event_out) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    hipEvent_t e;
+    RPH_HIP_CHECK(hipEventCreate(&e));
+    *event_out = e;
+    return RPH_OK;
+}
+int rph_event_record(rph_ctx *ctx, void *event, void *stream)
+{
+    if (!ctx || !event) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipEventRecord((hipEvent_t)event, pick(ctx, stream)));
+    return RPH_OK;
+}
+int rph_event_elapsed_ms(rph_ctx *ctx, void *start, void *stop, float *ms)
+{
+    if (!ctx || !start || !stop || !ms) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+    RPH_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return RPH_OK;
+}
+int rph_event_destroy(rph_ctx *ctx, void *event)
+{
+    if (!ctx || !event) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
+    return RPH_OK;
+}
+
+}  // extern "C"

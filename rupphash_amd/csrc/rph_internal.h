@@ -1,0 +1,56 @@
+// rph_internal.h -- shared by the translation units of librupphash_hip.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <mutex>
+
+#include "../../include/rupphash.h"
+
+struct rph_ctx {
+    int device = 0;
+    int compute_units = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    // scratch for the generic (multi-pass) PDQ kernel: two f32 planes per in-flight image
+    float *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int pdq_kernel = 1;  // 1 = fused 512x512x3 kernel where it applies, 0 = always generic
+};
+
+void rph_set_error(const char *fmt, ...);
+
+#define RPH_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            rph_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? RPH_ERR_OOM : RPH_ERR_HIP;                    \
+        }                                                                                    \
+    } while (0)
+
+// ---- launchers implemented in the .hip files (all asynchronous on `stream`) ----
+// pdq_kernels.hip
+int rph_launch_pdq_generic(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels,
+                           size_t row_stride, size_t image_stride, uint8_t *d_hash, float *d_quality, float *d_coeffs,
+                           uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream);
+int rph_launch_pdq_fused512(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, size_t row_stride, size_t image_stride,
+                            uint8_t *d_hash, float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid,
+                            hipStream_t stream);
+int rph_launch_pdq_from_coeffs(const float *d_coeffs, uint32_t n, uint8_t *d_hash, uint8_t *d_dihedral, hipStream_t stream);
+// hamming_kernels.hip
+int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
+                             const uint8_t *d_has_features, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts, rph_edge *d_edges,
+                             uint64_t cap, unsigned long long *d_count, hipStream_t stream);
+int rph_launch_mih_build256(rph_ctx *ctx, const uint8_t *d_hashes, uint64_t n, uint32_t *d_offsets, uint32_t *d_values,
+                            hipStream_t stream);
+// synth_kernels.hip
+int rph_launch_synth_images(uint8_t *d_out, uint64_t first_k, uint32_t n, uint32_t w, uint32_t h, uint32_t seed,
+                            hipStream_t stream);
+int rph_launch_synth_hashes(uint8_t *d_out, uint64_t first, uint64_t count, uint64_t n_total, uint64_t seed,
+                            uint64_t n_clusters, hipStream_t stream);
+
+// host_grouping.cpp
+int rph_host_union_find(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,
+                        uint32_t *n_groups_out);
+int rph_host_find_groups(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,
+                         uint32_t *n_groups_out);

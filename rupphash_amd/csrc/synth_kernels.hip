@@ -1,0 +1,145 @@
+// synth_kernels.hip -- device generators for the synthetic workloads of SURVEY.md 8(d).
+// Integer-only, counter based: the same functions as oracle/synth_ref.c state on the CPU
+// (tests compare them byte for byte), so benchmark inputs never cross PCIe.
+#include "rph_internal.h"
+
+namespace {
+
+constexpr uint64_t GOLDEN64 = 0x9E3779B97F4A7C15ull;
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += GOLDEN64;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h)
+{
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// One thread produces 4 consecutive bytes (one dword) of the packed RGB8 stream of an image.
+__global__ void __launch_bounds__(256) synth_images_kernel(uint32_t *__restrict__ out, uint64_t first_k, uint32_t n,
+                                                           uint32_t w, uint32_t h, uint32_t seed)
+{
+    const uint64_t dwords_per_img = ((uint64_t)w * h * 3 + 3) / 4;
+    const uint64_t total = dwords_per_img * n;
+    const uint32_t bytes_per_img = w * h * 3;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t img = (uint32_t)(t / dwords_per_img);
+        const uint32_t dw = (uint32_t)(t - (uint64_t)img * dwords_per_img);
+        const uint64_t k = first_k + img;
+        const uint64_t base = (k % 1000ull == 999ull) ? k - 1 : k;
+        const uint32_t bkey = mix32(seed ^ mix32((uint32_t)base * 0x9E3779B1u + (uint32_t)(base >> 32) + 0x1234567u));
+        const uint32_t nkey = (seed ^ 0x5EED5EEDu) + (uint32_t)k * 0x9E3779B1u + (uint32_t)(k >> 32) * 0x7FEB352Du;
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t idx = dw * 4 + b;  // byte index inside the image = (y*w + x)*3 + c
+            if (idx < bytes_per_img) {
+                const uint32_t pix = idx / 3, c = idx - pix * 3;
+                const uint32_t y = pix / w, x = pix - y * w;
+                const uint32_t bx = (x * 16) / w, by = (y * 16) / h;
+                const uint32_t col = mix32(bkey + ((by * 16u + bx) * 3u + c) * 0x85EBCA77u) & 0xFFu;
+                const uint32_t nz = mix32(nkey + idx * 0xC2B2AE3Du) & 15u;
+                int v = (int)col + (int)nz - 8;
+                v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                word |= (uint32_t)v << (8 * b);
+            }
+        }
+        // images are packed back to back; w*h*3 is a multiple of 4 for every geometry the launcher accepts
+        out[(uint64_t)img * (bytes_per_img / 4) + dw] = word;
+    }
+}
+
+__device__ __forceinline__ void hash_words(uint64_t seed, uint64_t i, uint64_t w[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = splitmix64(seed + (4 * i + (uint64_t)k) * GOLDEN64);
+}
+
+__global__ void __launch_bounds__(256) synth_hashes_kernel(uint64_t *__restrict__ out, uint64_t first, uint64_t count,
+                                                           uint64_t seed)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t w[4];
+        hash_words(seed, first + i, w);
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[i * 4 + k] = w[k];
+    }
+}
+
+// One thread per cluster member (c, j); cluster id n_clusters is the special distance-32 pair.
+__global__ void __launch_bounds__(256) synth_inject_kernel(uint64_t *__restrict__ out, uint64_t first, uint64_t count,
+                                                           uint64_t n_total, uint64_t seed, uint64_t n_clusters)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t c = t / 5;
+    const int j = (int)(t - c * 5);
+    if (c > n_clusters) return;
+    const bool special = (c == n_clusters);
+    if (special && j >= 2) return;
+    const uint64_t M = n_total / 5;
+    const uint64_t mul = (M % 7919ull == 0) ? 1 : 7919ull;
+    const uint64_t idx = (uint64_t)j * M + (c * mul) % M;
+    if (idx < first || idx >= first + count) return;
+    uint64_t w[4];
+    hash_words(seed ^ 0xC1A57E55EEDull, c, w);
+    if (special) {
+        if (j == 1)
+            for (int k = 0; k < 4; k++) w[k] ^= 0x0003000300030003ull;
+    } else {
+        const int pop = j == 0 ? 0 : (j == 1 ? 1 : (j == 2 ? 2 : (j == 3 ? 8 : 16)));
+        for (int b = 0; b < pop; b++) {
+            const uint32_t pos = (uint32_t)((c * 31 + (uint64_t)j * 11 + (uint64_t)b * 37) & 255);
+            w[pos >> 6] ^= 1ull << (pos & 63);
+        }
+    }
+    for (int k = 0; k < 4; k++) out[(idx - first) * 4 + k] = w[k];
+}
+
+}  // namespace
+
+int rph_launch_synth_images(uint8_t *d_out, uint64_t first_k, uint32_t n, uint32_t w, uint32_t h, uint32_t seed,
+                            hipStream_t stream)
+{
+    if (n == 0) return RPH_OK;
+    if (((uint64_t)w * h * 3) % 4 != 0) {
+        rph_set_error("rph_synth_images_dev: w*h*3 must be a multiple of 4 (got %ux%u)", w, h);
+        return RPH_ERR_INVALID_ARG;
+    }
+    const uint64_t total = ((uint64_t)w * h * 3 / 4) * n;
+    const uint64_t want = (total + 255) / 256;
+    const unsigned grid = (unsigned)(want < 65536 ? want : 65536);
+    hipLaunchKernelGGL(synth_images_kernel, dim3(grid), dim3(256), 0, stream, (uint32_t *)d_out, first_k, n, w, h, seed);
+    RPH_HIP_CHECK(hipGetLastError());
+    return RPH_OK;
+}
+
+int rph_launch_synth_hashes(uint8_t *d_out, uint64_t first, uint64_t count, uint64_t n_total, uint64_t seed,
+                            uint64_t n_clusters, hipStream_t stream)
+{
+    if (count == 0) return RPH_OK;
+    if (n_total >= 5 && n_clusters + 1 > n_total / 5) {
+        rph_set_error("rph_synth_hashes_dev: n_clusters + 1 must be <= n_total / 5");
+        return RPH_ERR_INVALID_ARG;
+    }
+    const uint64_t want = (count + 255) / 256;
+    const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL(synth_hashes_kernel, dim3(grid), dim3(256), 0, stream, (uint64_t *)d_out, first, count, seed);
+    RPH_HIP_CHECK(hipGetLastError());
+    if (n_total >= 5) {
+        const uint64_t members = (n_clusters + 1) * 5;
+        hipLaunchKernelGGL(synth_inject_kernel, dim3((unsigned)((members + 255) / 256)), dim3(256), 0, stream,
+                           (uint64_t *)d_out, first, count, n_total, seed, n_clusters);
+        RPH_HIP_CHECK(hipGetLastError());
+    }
+    return RPH_OK;
+}

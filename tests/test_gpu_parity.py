@@ -1,0 +1,326 @@
+"""GPU parity tests (-m gpu): every result that crosses the C ABI is compared bit for bit with the
+CPU oracle on the same seeded inputs; full-size runs are checked through construction-known answers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from rupphash_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def edge_set(edges):
+    return sorted((int(e["i"]), int(e["j"]), int(e["d"])) for e in edges)
+
+
+def clustered_hashes(rng, n, n_clusters, max_flip, members=4):
+    hashes = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for _ in range(n_clusters):
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        for j in rng.choice(n, members, replace=False):
+            v = base.copy()
+            for b in rng.choice(256, rng.integers(0, max_flip + 1), replace=False):
+                v[b // 8] ^= 1 << (b % 8)
+            hashes[j] = v
+    return hashes
+
+
+# ------------------------------------------------------------------ synthetic generators
+def test_synth_images_match_oracle(eng, oracle):
+    for first_k, n, w, h in [(0, 2, 512, 512), (998, 3, 512, 512), (5, 3, 100, 36), (2**33 + 7, 2, 64, 64)]:
+        got = eng.synth_images(first_k, n, w, h)
+        want = oracle.synth_images(first_k, n, w, h)
+        assert np.array_equal(got, want), (first_k, n, w, h)
+    # k % 1000 == 999 shares its blocks with k - 1 (near duplicate), different noise
+    pair = eng.synth_images(998, 2)
+    diff = np.abs(pair[0].astype(int) - pair[1].astype(int))
+    assert 0 < diff.max() <= 15
+
+
+def test_synth_hashes_match_oracle(eng, oracle):
+    n, nc = 50_000, 100
+    assert np.array_equal(eng.synth_hashes(0, n, n, n_clusters=nc), oracle.synth_hashes(0, n, n, n_clusters=nc))
+    assert np.array_equal(eng.synth_hashes(12_345, 7_000, n, n_clusters=nc), oracle.synth_hashes(12_345, 7_000, n, n_clusters=nc))
+    assert np.array_equal(eng.synth_hashes(0, 3, 3), oracle.synth_hashes(0, 3, 3))
+
+
+# ------------------------------------------------------------------ PDQ
+GEOMS = [(512, 512, 3), (5, 5, 3), (64, 64, 1), (100, 37, 3), (512, 300, 4), (333, 512, 3), (511, 509, 3), (7, 500, 1),
+         (129, 65, 3)]
+
+
+@pytest.mark.parametrize("w,h,ch", GEOMS)
+def test_pdq_generic_kernel_matches_oracle(eng, oracle, w, h, ch):
+    rng = np.random.default_rng(w * 1000 + h + ch)
+    n = 3
+    if ch == 1:
+        imgs = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    else:
+        imgs = rng.integers(0, 256, (n, h, w, ch), dtype=np.uint8)
+        # smooth structure so the hash is not pure noise: add a gradient to image 0
+        imgs[0, ..., 0] = (np.arange(w)[None, :] * 255 // max(w - 1, 1)).astype(np.uint8)
+    eng.set_pdq_kernel(0)
+    out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
+    eng.set_pdq_kernel(1)
+    for k in range(n):
+        rc, coeffs, q = oracle.pdq_features(imgs[k])
+        assert rc == 0 and out["valid"][k] == 1
+        assert np.array_equal(bits(out["coeffs"][k]), bits(coeffs)), f"coefficients differ for image {k}"
+        assert bits(out["quality"][k:k + 1])[0] == bits(np.float32(q))[()]
+        assert np.array_equal(out["hash"][k], oracle.to_hash(coeffs))
+        assert np.array_equal(out["dihedral"][k], oracle.dihedral_hashes(coeffs))
+
+
+def test_pdq_special_images(eng, oracle):
+    """flat image (quality 0, all coefficients tie), black, white, checkerboard, single bright pixel."""
+    h = w = 96
+    flat = np.full((h, w, 3), 128, np.uint8)
+    black = np.zeros((h, w, 3), np.uint8)
+    white = np.full((h, w, 3), 255, np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    checker = np.repeat((((yy // 8 + xx // 8) % 2) * 255).astype(np.uint8)[..., None], 3, axis=2)
+    dot = black.copy()
+    dot[40, 50] = 255
+    imgs = np.stack([flat, black, white, checker, dot])
+    eng.set_pdq_kernel(0)
+    out = eng.pdq_hash_batch(imgs, want_coeffs=True, want_dihedral=True)
+    eng.set_pdq_kernel(1)
+    for k in range(len(imgs)):
+        rc, coeffs, q = oracle.pdq_features(imgs[k])
+        assert np.array_equal(bits(out["coeffs"][k]), bits(coeffs)), k
+        assert out["quality"][k] == np.float32(q)
+        assert np.array_equal(out["hash"][k], oracle.to_hash(coeffs)), k
+        assert np.array_equal(out["dihedral"][k], oracle.dihedral_hashes(coeffs)), k
+    assert out["quality"][0] == 0.0
+
+
+def test_pdq_none_and_unsupported(eng):
+    from rupphash_amd import RphError, pdqhash
+
+    out = eng.pdq_hash_batch(np.zeros((2, 4, 64, 3), np.uint8))
+    assert not out["valid"].any() and not out["hash"].any()
+    assert pdqhash.generate_pdq(np.zeros((64, 4, 3), np.uint8), eng) is None        # pdqhash.rs:167-169
+    assert pdqhash.generate_pdq_features(np.zeros((5, 5, 3), np.uint8), eng) is not None
+    with pytest.raises(RphError) as e:
+        eng.pdq_hash_batch(np.zeros((1, 513, 16, 3), np.uint8))
+    assert e.value.status == -5
+
+
+def lcg_features(seed):
+    state = np.uint32(seed)
+    out = np.zeros(256, np.float32)
+    with np.errstate(over="ignore"):
+        for i in range(256):
+            state = np.uint32(state * np.uint32(1664525) + np.uint32(1013904223))
+            out[i] = np.float32(np.float32(int(state) >> 8) / np.float32(65536.0)) - np.float32(128.0)
+    return out
+
+
+def test_hashes_from_coeffs_match_oracle_and_reference_properties(eng, oracle):
+    """pdqhash.rs:548-570 on the GPU: to_hash / generate_dihedral_hashes == naive composition; 8 distinct."""
+    from rupphash_amd.pdqhash import PdqFeatures
+
+    feats = [lcg_features(s) for s in (1, 42, 0x12345678, 0xDEADBEEF, 7)]
+    rng = np.random.default_rng(9)
+    feats += [rng.normal(0, 30, 256).astype(np.float32) for _ in range(20)]
+    ties = np.zeros(256, np.float32)
+    ties[:100] = -0.0
+    ties[200:] = 1.0
+    feats += [ties, np.zeros(256, np.float32), np.arange(256, dtype=np.float32) - 127.5]
+    hashes, dih = eng.pdq_hashes_from_coeffs(np.stack(feats))
+    for k, f in enumerate(feats):
+        assert np.array_equal(hashes[k], oracle.to_hash(f)), k
+        assert np.array_equal(dih[k], oracle.dihedral_hashes(f)), k
+        assert np.array_equal(dih[k], oracle.naive_dihedral(f)), k
+    assert len({bytes(x) for x in dih[4]}) == 8
+    f = PdqFeatures(feats[0])
+    assert np.array_equal(f.to_hash(eng), hashes[0]) and np.array_equal(f.generate_dihedral_hashes(eng), dih[0])
+
+
+def test_dihedral_hashes_match_physically_transformed_image(eng, oracle):
+    """pdqhash.rs:583-628 end to end on the GPU: hashing a transposed / mirrored 64x64 Luma8 image
+    (windows are 1, so the 64x64 buffer is the image itself) lands exactly on the predicted slot."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    n = 64
+    tr = {0: img, 1: img[::-1, :].T, 2: img[::-1, ::-1], 3: img.T[::-1, :], 4: img[:, ::-1], 5: img[::-1, :], 6: img.T,
+          7: img[::-1, ::-1].T}
+    # the reference's transform(): out[x][y] = in[N-1-y][x] for variant 1, etc.
+    assert tr[1][3, 5] == img[n - 1 - 5, 3] and tr[3][3, 5] == img[5, n - 1 - 3] and tr[7][3, 5] == img[n - 1 - 5, n - 1 - 3]
+    eng.set_pdq_kernel(0)
+    base = eng.pdq_hash_batch(img[None], want_dihedral=True)["dihedral"][0]
+    got = eng.pdq_hash_batch(np.stack([np.ascontiguousarray(tr[v]) for v in range(8)]))["hash"]
+    eng.set_pdq_kernel(1)
+    for v in range(8):
+        assert np.array_equal(got[v], base[v]), v
+
+
+# ------------------------------------------------------------------ Hamming sweep
+@pytest.mark.parametrize("thr", [0, 10, 31, 32, 36, 37, 48, 49, 60, 61, 74, 75, 100])
+def test_all_pairs_matches_brute_force(eng, oracle, thr):
+    rng = np.random.default_rng(300 + thr)
+    hashes = clustered_hashes(rng, 2500, 60, min(thr + 20, 120))
+    got = eng.hamming_all_pairs(hashes, thr)
+    want = oracle.all_pairs256(hashes, thr)
+    assert edge_set(got) == sorted(map(tuple, want.tolist()))
+
+
+def test_all_pairs_sharded_over_parts(eng, oracle):
+    rng = np.random.default_rng(77)
+    hashes = clustered_hashes(rng, 5000, 80, 40)
+    want = sorted(map(tuple, oracle.all_pairs256(hashes, 32).tolist()))
+    for nparts in (2, 3, 8):
+        parts = [edge_set(eng.hamming_all_pairs(hashes, 32, part=p, nparts=nparts)) for p in range(nparts)]
+        merged = sorted(sum(parts, []))
+        assert merged == want and sum(len(p) for p in parts) == len(want)
+
+
+def test_all_pairs_edge_cases(eng):
+    assert len(eng.hamming_all_pairs(np.zeros((0, 32), np.uint8), 10)) == 0
+    assert len(eng.hamming_all_pairs(np.zeros((1, 32), np.uint8), 10)) == 0
+    same = np.tile(np.arange(32, dtype=np.uint8), (40, 1))
+    e = eng.hamming_all_pairs(same, 0)
+    assert len(e) == 40 * 39 // 2 and (e["d"] == 0).all() and (e["i"] < e["j"]).all()
+    far = np.stack([np.zeros(32, np.uint8), np.full(32, 255, np.uint8)])
+    assert edge_set(eng.hamming_all_pairs(far, 256)) == [(0, 1, 256)] and len(eng.hamming_all_pairs(far, 255)) == 0
+    # capacity protocol
+    import ctypes as C
+
+    from rupphash_amd import EDGE_DTYPE
+
+    buf = np.zeros(10, EDGE_DTYPE)
+    found = C.c_uint64()
+    rc = eng.L.rph_hamming_all_pairs(eng.ctx, same.ctypes.data, 40, 0, 0, 1, buf.ctypes.data, 10, C.byref(found))
+    assert rc == -6 and found.value == 780 and (buf["i"] < buf["j"]).all()
+
+
+@pytest.mark.parametrize("thr", [0, 5, 15, 16, 20, 31, 32, 40])
+def test_find_groups_matches_reference_semantics(eng, oracle, thr):
+    """hamminghash.rs:191-271 bit-exact, including group-internal member order and the R<=1 reachability gap."""
+    rng = np.random.default_rng(400 + thr)
+    hashes = clustered_hashes(rng, 3000, 70, 36, members=5)
+    a = np.zeros(32, np.uint8)
+    b = np.zeros(32, np.uint8)
+    b[0::2] = 0x03  # d = 32, two bits in every 16-bit chunk: unreachable by R<=1 probing
+    hashes[100], hashes[2000] = a, b
+    assert eng.find_groups256(hashes, thr) == oracle.find_groups(oracle.KIND_PDQ, hashes, thr)
+
+
+def test_find_groups_reference_tests_on_gpu(eng):
+    """hamminghash.rs:310-331 through the mirror module."""
+    from rupphash_amd import hamminghash as hh
+
+    base = np.zeros(32, np.uint8)
+    target = np.zeros(32, np.uint8)
+    for i in range(30):
+        target[i // 8] |= 1 << (i % 8)
+    idx = hh.MIHIndex(np.stack([base, target]), eng)
+    assert hh.find_groups(idx, 30) == [[0, 1]]
+    assert idx.len() == 2 and list(idx.bucket(15, 0)) == [0, 1] and list(idx.bucket(0, 0xFFFF)) == [1]
+
+
+@pytest.mark.parametrize("sim", [0, 16, 31, 40, 63])
+def test_group_files_pdq_matches_oracle(eng, oracle, sim):
+    """scanner.rs:1640-1823: 8 dihedral variants of file i against hash j > i, low-confidence rule, union-find."""
+    rng = np.random.default_rng(500 + sim)
+    n = 1500
+    coeffs = rng.normal(0, 20, (n, 256)).astype(np.float32)
+    # near-duplicate coefficient sets (small perturbations) and a mirrored copy (sign flip on odd-frequency columns)
+    for c in range(40):
+        src = rng.integers(0, n)
+        for j in rng.choice(n, 3, replace=False):
+            coeffs[j] = coeffs[src] + rng.normal(0, 0.8, 256).astype(np.float32)
+    mirrored = coeffs[10].reshape(16, 16).copy()
+    mirrored[:, 0::2] *= -1
+    coeffs[1400] = mirrored.ravel()
+    hashes, dih = eng.pdq_hashes_from_coeffs(coeffs)
+    quality = rng.integers(30, 101, n).astype(np.int32)
+    quality[::7] = -1
+    has_features = (rng.random(n) > 0.1).astype(np.uint8)
+    var = dih.copy()
+    want_edges, want_groups = oracle.group_pdq(hashes, sim, variants=var, has_features=has_features, quality=quality)
+    groups, cmp_count = eng.group_files_pdq(hashes, sim, coeffs=coeffs, has_features=has_features, quality=quality)
+    assert groups == want_groups and cmp_count == len(want_edges)
+    # edge multiset through the variant sweep entry point
+    v2 = var.copy()
+    v2[has_features == 0] = hashes[has_features == 0][:, None, :]
+    low = np.array([oracle.lib().rph_ref_is_low_pdq_quality(int(q)) for q in quality], np.uint8)
+    e = eng.hamming_variant_pairs(v2, hashes, sim, low_conf=low)
+    keep = [(int(x["i"]), int(x["j"])) for x in e if has_features[x["i"]] or ((x["flags"] >> 9) & 7) == 0]
+    assert sorted(keep) == sorted(map(tuple, want_edges.tolist()))
+    # no features at all: single variant = the hash itself
+    g1, c1 = eng.group_files_pdq(hashes, sim, quality=quality)
+    we, wg = oracle.group_pdq(hashes, sim, quality=quality)
+    assert g1 == wg and c1 == len(we)
+
+
+def test_group_files_rejects_similarity_above_63(eng):
+    from rupphash_amd import RphError
+
+    with pytest.raises(RphError):
+        eng.group_files_pdq(np.zeros((4, 32), np.uint8), 64)
+
+
+def test_mih_build_matches_reference_csr(eng, oracle):
+    rng = np.random.default_rng(6)
+    hashes = rng.integers(0, 256, (20_000, 32), dtype=np.uint8)
+    hashes[:, 4] &= 0x03  # crowded buckets in chunk 2
+    hashes[5000:5100] = hashes[0]
+    off, vals = eng.mih_build256(hashes)
+    woff, wvals = oracle.MIHIndex(oracle.KIND_PDQ, hashes).csr()
+    assert np.array_equal(off, woff) and np.array_equal(vals, wvals)
+
+
+# ------------------------------------------------------------------ full-size, construction-known answers
+def test_one_million_hashes_threshold_32(eng, oracle):
+    """BASELINE config 3: 1M synthetic hashes, 1000 injected 5-member clusters + the distance-32 pair.
+    The expected edge set follows from the construction (random 256-bit pairs at d <= 32 have
+    probability ~1e-33), so the full-size sweep is checked exactly."""
+    n, nc = 1_000_000, 1000
+    d_h = eng.dev_alloc(n * 32)
+    cap = 1 << 16
+    d_e = eng.dev_alloc(cap * 12)
+    d_c = eng.dev_alloc(8)
+    try:
+        eng.synth_hashes_dev(d_h, 0, n, n, n_clusters=nc)
+        eng.dev_memset(d_c, 0, 8)
+        eng.hamming_all_pairs_dev(d_h, n, 32, d_e, cap, d_c)
+        eng.synchronize()
+        cnt = np.zeros(1, np.uint64)
+        eng.dev_download(cnt, d_c)
+        from rupphash_amd import EDGE_DTYPE
+
+        edges = np.zeros(int(cnt[0]), EDGE_DTYPE)
+        eng.dev_download(edges, d_e)
+    finally:
+        for p in (d_h, d_e, d_c):
+            eng.dev_free(p)
+    pops = [0, 1, 2, 8, 16]
+    want = []
+    for c in range(nc):
+        idx = [oracle.synth_cluster_index(n, c, j) for j in range(5)]
+        masks = []
+        for j in range(5):
+            m = 0
+            for t in range(pops[j]):
+                m |= 1 << ((c * 31 + j * 11 + t * 37) & 255)
+            masks.append(m)
+        for a in range(5):
+            for b in range(a + 1, 5):
+                i, j = sorted((idx[a], idx[b]))
+                want.append((i, j, bin(masks[a] ^ masks[b]).count("1")))
+    i, j = sorted((oracle.synth_cluster_index(n, nc, 0), oracle.synth_cluster_index(n, nc, 1)))
+    want.append((i, j, 32))
+    assert edge_set(edges) == sorted(want)
+    special = [e for e in edges if e["d"] == 32 and (int(e["i"]), int(e["j"])) == (i, j)][0]
+    assert not (special["flags"] & 0x8000)  # unreachable for find_groups' R<=1 probing
