@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- PDQ hashes/s (512x512 RGB8) + 256-bit Hamming Gpairs/s on 1..8 MI355X.
+
+A "step" is one pass of the hot path over one resident batch:
+  phase A (-> `value`): PDQ-hash `--images` synthetic 512x512 RGB8 images per GPU (BASELINE config 2:
+           100 000 images on 1 GPU; weak scaling: every rank hashes its own 100 000);
+  phase B (-> `hamming`): all-pairs 256-bit Hamming sweep, threshold 32, over 1M*sqrt(N) synthetic
+           hashes (BASELINE config 3 at N=1; per-GPU pair count fixed as N grows): every rank generates
+           its shard, one RCCL all-gather of the hash shards, then each rank sweeps its share of the tile pairs.
+Inputs are generated on the device and resident in HBM before the timed region.
+One JSON line on rank 0.  Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under
+torch.distributed.run (one process per GPU).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IMG_BYTES = 512 * 512 * 3
+ALGO_BYTES_PER_IMAGE = IMG_BYTES + 32          # 786 432 B read + 32 B hash written
+HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--images", type=int, default=100_000, help="images per GPU per step")
+    ap.add_argument("--hashes", type=int, default=1_000_000, help="hashes at N=1 (scaled by sqrt(N))")
+    ap.add_argument("--threshold", type=int, default=32)
+    ap.add_argument("--hamming-steps", type=int, default=0, help="default: same as --steps")
+    ap.add_argument("--pdq-kernel", type=int, default=1, help="1 = fused 512x512 kernel, 0 = generic multi-pass")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+
+    from rupphash_amd import EDGE_DTYPE, Engine
+
+    eng = Engine(local_rank)
+    eng.set_pdq_kernel(args.pdq_kernel)
+    dev = torch.device("cuda", local_rank)
+    # one explicit (non-null) HIP stream carries the kernels, torch's fills and the RCCL collective, so the
+    # HIP events below bracket exactly the work they name
+    ts = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(ts)
+    stream = ts.cuda_stream
+
+    def barrier_sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------------------------ phase A: PDQ hashing
+    n_img = args.images
+    imgs = torch.empty((n_img, IMG_BYTES), dtype=torch.uint8, device=dev)
+    hashes = torch.empty((n_img, 32), dtype=torch.uint8, device=dev)
+    first_k = rank * n_img  # every rank hashes its own contiguous range of the global image sequence
+    eng.synth_images_dev(imgs.data_ptr(), first_k, n_img, 512, 512, stream=stream)
+    torch.cuda.synchronize()
+
+    def pdq_step():
+        eng.pdq_hash_batch_dev(imgs.data_ptr(), n_img, 512, 512, 3, hashes.data_ptr(), stream=stream)
+
+    for _ in range(args.warmup):
+        pdq_step()
+    ev = [(eng.event(), eng.event()) for _ in range(args.steps)]
+    barrier_sync()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        eng.event_record(ev[s][0], stream)
+        pdq_step()
+        eng.event_record(ev[s][1], stream)
+    barrier_sync()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    kernel_ms = [eng.event_elapsed_ms(a, b) for a, b in ev]
+    for a, b in ev:
+        eng.event_destroy(a)
+        eng.event_destroy(b)
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    value = world * n_img * args.steps / elapsed
+    achieved_gbs = ALGO_BYTES_PER_IMAGE * n_img / (avg_kernel_ms * 1e-3) / 1e9
+    hash_checksum = int(hashes.to(torch.int64).sum().item())
+    pdq_sample = hashes[:64].cpu().numpy()
+    img_sample = imgs[:64].cpu().numpy().reshape(64, 512, 512, 3)
+
+    # ------------------------------------------------------------------ phase B: Hamming sweep
+    del imgs
+    torch.cuda.empty_cache()
+    n_h = int(round(args.hashes * math.sqrt(world) / (1024 * world))) * 1024 * world if args.hashes >= 1024 * world else args.hashes
+    shard = n_h // world
+    n_clusters = min(1000, max(0, n_h // 5 - 1))
+    all_h = torch.empty((n_h, 32), dtype=torch.uint8, device=dev)
+    mine = all_h[rank * shard:(rank + 1) * shard]
+    cap = 1 << 20
+    d_edges = torch.empty((cap, 12), dtype=torch.uint8, device=dev)
+    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    h_steps = args.hamming_steps or args.steps
+
+    def hamming_step():
+        # exchange step: every rank contributes its shard of hashes (in a real scan: the hashes it just computed)
+        eng.synth_hashes_dev(mine.data_ptr(), rank * shard, shard, n_h, n_clusters=n_clusters, stream=stream)
+        if dist is not None:
+            dist.all_gather_into_tensor(all_h, mine)
+        d_count.zero_()
+        eng.hamming_all_pairs_dev(all_h.data_ptr(), n_h, args.threshold, d_edges.data_ptr(), cap, d_count.data_ptr(),
+                                  part=rank, nparts=world, stream=stream)
+
+    for _ in range(max(1, min(args.warmup, 1))):
+        hamming_step()
+    hev = [(eng.event(), eng.event()) for _ in range(h_steps)]
+    barrier_sync()
+    t0 = time.perf_counter()
+    for s in range(h_steps):
+        eng.event_record(hev[s][0], stream)
+        hamming_step()
+        eng.event_record(hev[s][1], stream)
+    barrier_sync()
+    h_elapsed = max_over_ranks(time.perf_counter() - t0)
+    h_kernel_ms = sum(eng.event_elapsed_ms(a, b) for a, b in hev) / h_steps
+    n_pairs = n_h * (n_h - 1) // 2
+    gpairs = n_pairs * h_steps / h_elapsed / 1e9
+    n_edges_local = int(d_count.item())
+    n_edges = n_edges_local
+    if dist is not None:
+        t = torch.tensor([n_edges_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        n_edges = int(t.item())
+    expected_edges = n_clusters * 10 + (1 if n_h >= 10 else 0)
+    pw = 4 if args.threshold <= 36 else 5 if args.threshold <= 48 else 6 if args.threshold <= 60 else 7 if args.threshold <= 74 else 8
+    lane_ops = 2 * pw * (n_pairs / world) / (h_kernel_ms * 1e-3)  # executed xor+bcnt lane-ops/s on this rank
+
+    result = {
+        "metric": "pdq_hashes_per_sec_512x512_rgb",
+        "value": value,
+        "unit": "hashes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"batch PDQ hash of {n_img} synthetic 512x512 RGB8 images per GPU, resident in HBM "
+                               "(BASELINE config 2), hash-only output",
+                   "images_per_gpu": n_img, "image": "512x512x3 u8", "pdq_kernel": "fused512" if args.pdq_kernel else "generic",
+                   "hash_checksum": hash_checksum},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": avg_kernel_ms, "algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE},
+        "hamming": {"metric": "hamming256_pair_comparisons_per_sec", "value": gpairs, "unit": "Gpairs/s",
+                    "n_hashes": n_h, "threshold": args.threshold, "steps": h_steps, "ms_per_step": h_elapsed / h_steps * 1e3,
+                    "scaling": "weak (pairs per GPU fixed: n = 1M*sqrt(N))", "edges_found": n_edges,
+                    "edges_expected": expected_edges,
+                    "exchange": "RCCL all-gather of hash shards" if world > 1 else "none (1 GPU)",
+                    "roofline": {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
+                                 "unit": "Tlane-op/s", "frac": lane_ops / VALU_LANE_OPS_PER_S, "prefix_dwords": pw,
+                                 "lane_ops_per_pair": 2 * pw, "hbm_bytes_per_pair": 64.0 / 1024, "kernel_ms": h_kernel_ms}},
+    }
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle
+
+        cores = os.cpu_count() or 1
+        # PDQ: the oracle on the first images of the same synthetic sequence, one image per task over all cores
+        t_pilot, hp, _ = oracle.bench_pdq(img_sample[:cores], cores)
+        per_img = max(t_pilot / cores, 1e-4)
+        n_cpu = int(min(max(args.cpu_seconds / per_img, cores), 4096))
+        cpu_imgs = img_sample if n_cpu <= 64 else oracle.synth_images(0, n_cpu)
+        cpu_imgs = cpu_imgs[:n_cpu]
+        secs, cpu_hashes, _ = oracle.bench_pdq(cpu_imgs, cores)
+        parity = bool(np.array_equal(cpu_hashes[:min(n_cpu, 64)], pdq_sample[:min(n_cpu, 64)]))
+        result["cpu_baseline"] = {"value": n_cpu / secs, "unit": "hashes/s", "cores": cores, "kind": "port",
+                                  "sample": f"{n_cpu} of the same synthetic 512x512 RGB8 images, C oracle, {cores} threads",
+                                  "gpu_hashes_equal_cpu_hashes_on_sample": parity}
+        # Hamming: brute-force XOR-popcount on a 64k subset (apples to apples), and the reference's own
+        # algorithm (MIH find_groups) on a timed query sample of the full 1M set
+        sub = all_h[:65536].cpu().numpy()
+        bsecs, _ = oracle.bench_all_pairs256(sub, args.threshold, cores)
+        full = all_h.cpu().numpy()
+        q_pilot = 20000
+        times, _ = oracle.bench_find_groups(oracle.KIND_PDQ, full, args.threshold, cores, q_limit=q_pilot)
+        q_rate = q_pilot / max(times[1], 1e-6)
+        result["hamming"]["cpu_baseline"] = {
+            "value": (65536 * 65535 / 2) / bsecs / 1e9, "unit": "Gpairs/s", "cores": cores, "kind": "port",
+            "sample": "brute-force XOR-popcount over all pairs of the first 65 536 hashes",
+            "mih_find_groups": {"index_build_s": times[0], "queries_per_s": q_rate,
+                                "extrapolated_s_for_all_queries": n_h / q_rate,
+                                "sample": f"MIHIndex::new on all {n_h} hashes + the first {q_pilot} queries of find_groups "
+                                          f"(max_dist {args.threshold}), {cores} threads"}}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
