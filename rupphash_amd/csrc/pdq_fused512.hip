@@ -1,7 +1,526 @@
-// placeholder until the fused kernel lands
+// pdq_fused512.hip -- fused single-pass PDQ hash of 512x512 RGB8 images for gfx950.
+//
+// Replaces, for this geometry, the whole of generate_pdq_from_luma + to_luma601
+// (/root/reference/src/pdqhash.rs:238-284, 341-460) and feeds the shared tail (pdq_tail.hpp).
+// The image is read from HBM exactly once (786 432 B); nothing but the outputs is written back.
+//
+// One wave (64 lanes) owns one image and never synchronises with another wave.  It walks the image
+// in 8 bands of 64 rows x 8 strips of 64 columns.  Per (band, strip) tile:
+//   LOAD   lane (c, g) = 8 columns x 8 rows: two global_load_dwordx3 per row, Rec.601 luma in f32
+//          (exact integers), packed to f16; the 7 luma rows above come from the lane with g-1
+//          through LDS (or from the previous band's saved rows), and the vertical 8-row window sums
+//          V (<= 2040, exact in f16) go to a 64x64 f16 tile in LDS.
+//   SCAN   lane r = image row: walks the tile left to right keeping the horizontal 8-window sum Hs
+//          of V in f32 (= the pass-1 box value x 64, an exact integer) and the reference's pass-2 row
+//          running sum (sum += in[ri]; sum -= in[li]) in the reference's order; emits the pass-2 row
+//          value at the 8 sampled columns x = 8j+4.
+// Twice per band the sampled values go through the pass-2 column chain (lane = sampled column), which
+// leaves B[i][j] in registers, lane j holding column j -- exactly what pdq_tail() consumes.
+//
+// Exactness (tests/test_fused_scheme.py proves each point against the sequential oracle):
+//   * pass 1 is an exact 8x8 integer box sum / 64 except on the frame: columns {0,1,2,508,509,510}
+//     (windows of 5,6,7 in the row pass) are inexact and their column pass is run as the reference's
+//     sequential running sum ("edge chains", 6 lanes); rows {0,1,2,508,509,510} divide an exact sum once.
+//   * all pass-2 quantities are carried scaled by 64 (power of two: commutes with f32 rounding).
+//   * no FMA contraction anywhere except where the operands are exact integers (luma).
+#include "pdq_tail.hpp"
 #include "rph_internal.h"
-int rph_launch_pdq_fused512(rph_ctx *, const uint8_t *, uint32_t, size_t, size_t, uint8_t *, float *, float *, uint8_t *,
-                            uint8_t *, hipStream_t)
+
+namespace {
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int TILE_PITCH = 144;                 // bytes per V-tile row: 64 f16 + 16 B pad (conflict-free b128 reads, lane = row)
+constexpr int OFF_TILE = 0;                     // 64 * 144 = 9216 B; the exchange area and the tail scratch alias it
+constexpr int OFF_STATE = 9216;                 // 7 luma rows x 512 columns, f16 = 7168 B
+constexpr int OFF_SAMP = OFF_STATE + 7168;      // 64 rows x 33 floats = 8448 B
+constexpr int SAMP_PITCH = 33;
+constexpr int OFF_EDGE = OFF_SAMP + 8448;       // 6 chains x 64 rows x f32 = 1536 B (rv in, edge values out, in place)
+constexpr int LDS_BYTES = OFF_EDGE + 1536;      // 26368 B -> 6 waves per CU
+static_assert(rph::TAIL_LDS_FLOATS * 4 <= 9216, "tail scratch must fit in the dead V tile");
+
+struct Px8 {  // 8 RGB pixels = 24 bytes = 6 dwords, loaded as 2 x dwordx3
+    uint32_t d[6];
+};
+struct __attribute__((packed, aligned(4))) U3 {
+    uint32_t x, y, z;
+};
+
+__device__ __forceinline__ Px8 load_px8(const uint8_t *p)
 {
-    return RPH_ERR_UNSUPPORTED;
+    const U3 a = *reinterpret_cast<const U3 *>(p);
+    const U3 b = *reinterpret_cast<const U3 *>(p + 12);
+    Px8 r;
+    r.d[0] = a.x; r.d[1] = a.y; r.d[2] = a.z; r.d[3] = b.x; r.d[4] = b.y; r.d[5] = b.z;
+    return r;
+}
+
+// to_luma601 (pdqhash.rs:270-273): (299 r + 587 g + 114 b + 500) / 1000, truncating.  In f32 every
+// intermediate is an integer < 2^24 (fma is exact) and trunc(num * 0.001f) equals the integer quotient
+// for every reachable numerator (tests/test_fused_scheme.py::test_luma_float_formula...).
+template <int P>
+__device__ __forceinline__ float luma_px(const Px8 &v)
+{
+    constexpr int B = 3 * P;
+    const float r = (float)((v.d[B >> 2] >> (8 * (B & 3))) & 0xFFu);
+    const float g = (float)((v.d[(B + 1) >> 2] >> (8 * ((B + 1) & 3))) & 0xFFu);
+    const float b = (float)((v.d[(B + 2) >> 2] >> (8 * ((B + 2) & 3))) & 0xFFu);
+    const float num = __builtin_fmaf(299.0f, r, __builtin_fmaf(587.0f, g, __builtin_fmaf(114.0f, b, 500.0f)));
+    return __builtin_truncf(num * 0.001f);
+}
+
+__device__ __forceinline__ void luma8(const Px8 &v, float (&l)[8])
+{
+    l[0] = luma_px<0>(v); l[1] = luma_px<1>(v); l[2] = luma_px<2>(v); l[3] = luma_px<3>(v);
+    l[4] = luma_px<4>(v); l[5] = luma_px<5>(v); l[6] = luma_px<6>(v); l[7] = luma_px<7>(v);
+}
+
+// 8 lumas -> 4 packed f16 pairs (integers <= 255: exact under any rounding mode)
+struct Row8 {
+    h2 q[4];
+};
+__device__ __forceinline__ Row8 pack_row(const Px8 &v, bool zero)
+{
+    float l[8];
+    luma8(v, l);
+    Row8 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        r.q[i] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(l[2 * i], l[2 * i + 1]));
+        if (zero) r.q[i] = h2{(_Float16)0, (_Float16)0};
+    }
+    return r;
+}
+__device__ __forceinline__ uint4 row_bits(const Row8 &r)
+{
+    uint4 u;
+    u.x = __builtin_bit_cast(uint32_t, r.q[0]);
+    u.y = __builtin_bit_cast(uint32_t, r.q[1]);
+    u.z = __builtin_bit_cast(uint32_t, r.q[2]);
+    u.w = __builtin_bit_cast(uint32_t, r.q[3]);
+    return u;
+}
+__device__ __forceinline__ Row8 bits_row(const uint4 &u)
+{
+    Row8 r;
+    r.q[0] = __builtin_bit_cast(h2, u.x);
+    r.q[1] = __builtin_bit_cast(h2, u.y);
+    r.q[2] = __builtin_bit_cast(h2, u.z);
+    r.q[3] = __builtin_bit_cast(h2, u.w);
+    return r;
+}
+
+// IEEE quotient N / d for the integer numerators that occur here (multiples of 8 below 2^22) and
+// d in {4,5,6,7,8}: Markstein's sequence, 1 mul + 2 fma (test_markstein_division_is_ieee...).
+__device__ __forceinline__ float div_small(float N, float d, float dinv)
+{
+    const float q0 = N * dinv;
+    const float r = __builtin_fmaf(-q0, d, N);
+    return __builtin_fmaf(r, dinv, q0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The kernel
+// ---------------------------------------------------------------------------------------------
+struct Wave {
+    uint8_t *lds;
+    const uint8_t *img;
+    size_t row_stride;
+    int lane;
+    // scan state (lane = row of the band), carried across the 8 strips of a band
+    float hs, sum, ring[8];
+    h8 pv;
+    float row_d, row_dinv;  // pass-1 column-window divisor of this lane's row (8 except on the frame)
+    // pass-2 column chain (lane = sampled column j), carried across the whole image
+    float csum, cring[8];
+    // edge chains (lanes 0..5), carried across the whole image
+    float ecs, ering[8];
+    float B[64];
+};
+
+__device__ __forceinline__ const uint8_t *tile_px(const Wave &w, int b, int s, int k, int c, int g, bool &beyond)
+{
+    int y = 64 * b + 4 + 8 * g + k;
+    beyond = y >= 512;
+    y = beyond ? 511 : y;
+    return w.img + (size_t)y * w.row_stride + (size_t)(64 * s + 8 * c) * 3;
+}
+
+// LOAD phase 1: issue the 16 loads of tile (b, s)
+__device__ __forceinline__ void tile_issue(const Wave &w, int b, int s, Px8 (&pre)[8])
+{
+    const int c = w.lane & 7, g = w.lane >> 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        bool beyond;
+        pre[k] = load_px8(tile_px(w, b, s, k, c, g, beyond));
+    }
+}
+
+// LOAD phase 2: luma, exchange of the 7 rows above, vertical window sums, V tile
+__device__ __forceinline__ void tile_build(Wave &w, int b, int s, const Px8 (&pre)[8])
+{
+    const int c = w.lane & 7, g = w.lane >> 3;
+    uint8_t *tile = w.lds + OFF_TILE;
+    uint8_t *state = w.lds + OFF_STATE + (64 * s + 8 * c) * 2;
+    Row8 L[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) L[k] = pack_row(pre[k], 64 * b + 4 + 8 * g + k >= 512);
+
+    // publish rows 1..7 for the lane below (g + 1); the tile is dead here (its scan is over)
+    if (g < 7) {
+        uint8_t *x = tile + ((g * 7) * 8 + c) * 16;
+#pragma unroll
+        for (int k = 1; k < 8; k++) *reinterpret_cast<uint4 *>(x + (k - 1) * 128) = row_bits(L[k]);
+    }
+    __syncthreads();
+    // the 7 luma rows above this lane's first row: from lane g-1, or for g == 0 from the previous band
+    Row8 hist[7];
+    {
+        const uint8_t *hp = (g == 0) ? state : tile + (((g - 1) * 7) * 8 + c) * 16;
+        const int stride = (g == 0) ? 1024 : 128;
+#pragma unroll
+        for (int j = 0; j < 7; j++) hist[j] = bits_row(*reinterpret_cast<const uint4 *>(hp + j * stride));
+    }
+    __syncthreads();
+    if (g == 7) {  // rows 1..7 of the last lane group are the next band's history for these columns
+#pragma unroll
+        for (int k = 1; k < 8; k++) *reinterpret_cast<uint4 *>(state + (k - 1) * 1024) = row_bits(L[k]);
+    }
+    // V[m] = sum of the 8 luma rows ending at own row m  (V row 64b + 8g + m = luma rows -3..+4 around it)
+    Row8 v;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        h2 a = hist[0].q[i] + hist[1].q[i];
+        h2 bb = hist[2].q[i] + hist[3].q[i];
+        h2 cc = hist[4].q[i] + hist[5].q[i];
+        h2 dd = hist[6].q[i] + L[0].q[i];
+        v.q[i] = (a + bb) + (cc + dd);
+    }
+    *reinterpret_cast<uint4 *>(tile + (8 * g + 0) * TILE_PITCH + 16 * c) = row_bits(v);
+#pragma unroll
+    for (int m = 1; m < 8; m++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v.q[i] = (v.q[i] - hist[m - 1].q[i]) + L[m].q[i];  // subtract first: stays <= 2040
+        *reinterpret_cast<uint4 *>(tile + (8 * g + m) * TILE_PITCH + 16 * c) = row_bits(v);
+    }
+    __syncthreads();
+}
+
+// one step of the pass-2 row chain: input in2 (scaled by 64) enters, the input 8 back leaves
+template <int E>
+__device__ __forceinline__ void row_step(Wave &w, float in2)
+{
+    constexpr int slot = (E + 4) & 7;  // ri mod 8 with ri = xv - 4
+    w.sum = w.sum + in2;
+    w.sum = w.sum - w.ring[slot];
+    w.ring[slot] = in2;
+}
+
+template <bool EDGE_ROWS>
+__device__ __forceinline__ float pass1_value(const Wave &w, float hs)
+{
+    // 64 x pass-1 value at an interior column: Hs (8x8 box sum) for full windows, one IEEE division on the frame rows
+    if (EDGE_ROWS) return div_small(hs * 8.0f, w.row_d, w.row_dinv);
+    return hs;
+}
+
+// SCAN of strip s of the current band.  FIRST/LAST: strip 0 / strip 7 (frame columns).
+template <bool EDGE_ROWS, bool FIRST, bool LAST>
+__device__ __forceinline__ void scan_strip(Wave &w, int s)
+{
+    const int r = w.lane;
+    const uint8_t *tp = w.lds + OFF_TILE + r * TILE_PITCH;
+    float *samp = reinterpret_cast<float *>(w.lds + OFF_SAMP) + r * SAMP_PITCH;
+    const float *edge = reinterpret_cast<const float *>(w.lds + OFF_EDGE);
+#pragma unroll 1
+    for (int q = 0; q < 8; q++) {
+        const h8 cur = *reinterpret_cast<const h8 *>(tp + 16 * q);
+        const bool first_octet = FIRST && q == 0;
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+        if (first_octet) {  // pass-1 values of columns 0,1,2 come from the edge chains
+            e0 = edge[0 * 64 + r];
+            e1 = edge[1 * 64 + r];
+            e2 = edge[2 * 64 + r];
+        }
+#define RPH_STEP(E)                                                              \
+    {                                                                            \
+        w.hs = w.hs + (float)cur[E];                                             \
+        w.hs = w.hs - (float)w.pv[E];                                            \
+        float in2 = pass1_value<EDGE_ROWS>(w, w.hs);                             \
+        if (first_octet && (E) == 4) in2 = e0;                                   \
+        if (first_octet && (E) == 5) in2 = e1;                                   \
+        if (first_octet && (E) == 6) in2 = e2;                                   \
+        if (!(first_octet && (E) < 4)) row_step<E>(w, in2); /* ri = xv - 4 >= 0 */ \
+    }
+        RPH_STEP(0) RPH_STEP(1) RPH_STEP(2) RPH_STEP(3) RPH_STEP(4)
+        // output o = xv - 8 = 8j + 4 right after element 4 of octet j + 1
+        if (!first_octet) {
+            const int j = 8 * s + q - 1;
+            samp[j < 31 ? j : j - 31] = w.sum * 0.125f;
+        }
+        RPH_STEP(5) RPH_STEP(6) RPH_STEP(7)
+#undef RPH_STEP
+        w.pv = cur;
+    }
+    if (LAST) {
+        // columns 508..511: V beyond the image is 0; 508,509,510 come from the edge chains, 511 has a 4-wide window
+        const float e3 = edge[3 * 64 + r], e4 = edge[4 * 64 + r], e5 = edge[5 * 64 + r];
+        w.hs = w.hs - (float)w.pv[0]; row_step<0>(w, e3);
+        w.hs = w.hs - (float)w.pv[1]; row_step<1>(w, e4);
+        w.hs = w.hs - (float)w.pv[2]; row_step<2>(w, e5);
+        w.hs = w.hs - (float)w.pv[3];
+        {
+            const float in511 = EDGE_ROWS ? div_small(w.hs * 16.0f, w.row_d, w.row_dinv) : w.hs * 2.0f;
+            row_step<3>(w, in511);
+        }
+        // phase 4, first step: out[508] = (sum - in[504]) / 7   (ring slot of ri = 504 is 0)
+        w.sum = w.sum - w.ring[0];
+        samp[63 - 31] = w.sum / 7.0f;
+    }
+}
+
+__device__ __forceinline__ void scan_reset(Wave &w, int b)
+{
+    w.hs = 0.f;
+    w.sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w.ring[i] = 0.f;
+    w.pv = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    // column-window size of row y = 64 b + lane: 5,6,7,8 | 8 ... | 7,6,5,4
+    const int y = 64 * b + w.lane;
+    const int lo = y - 3 < 0 ? 0 : y - 3, hi = y + 4 > 511 ? 511 : y + 4;
+    const float d = (float)(hi - lo + 1);
+    w.row_d = d;
+    w.row_dinv = 1.0f / d;
+}
+
+// store B[i] with a wave-uniform runtime i (registers cannot be indexed dynamically)
+__device__ __forceinline__ void store_B(Wave &w, int i, float v)
+{
+#define RPH_CASE8(base)                                                   \
+    case (base) + 0: w.B[(base) + 0] = v; break;                          \
+    case (base) + 1: w.B[(base) + 1] = v; break;                          \
+    case (base) + 2: w.B[(base) + 2] = v; break;                          \
+    case (base) + 3: w.B[(base) + 3] = v; break;                          \
+    case (base) + 4: w.B[(base) + 4] = v; break;                          \
+    case (base) + 5: w.B[(base) + 5] = v; break;                          \
+    case (base) + 6: w.B[(base) + 6] = v; break;                          \
+    case (base) + 7: w.B[(base) + 7] = v; break;
+    switch (i) {
+        RPH_CASE8(0) RPH_CASE8(8) RPH_CASE8(16) RPH_CASE8(24) RPH_CASE8(32) RPH_CASE8(40) RPH_CASE8(48) RPH_CASE8(56)
+        default: break;
+    }
+#undef RPH_CASE8
+}
+
+// pass-2 column chain over the 64 rows of band b for the sampled columns of one half (lanes [0,31) or [31,64))
+__device__ __forceinline__ void col_pass(Wave &w, int b, bool second_half)
+{
+    const bool active = second_half ? (w.lane >= 31) : (w.lane < 31);
+    if (!active) return;
+    const float *samp = reinterpret_cast<const float *>(w.lds + OFF_SAMP) + (second_half ? w.lane - 31 : w.lane);
+#pragma unroll 1
+    for (int u = 0; u < 8; u++) {
+        float in[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) in[e] = samp[(8 * u + e) * SAMP_PITCH];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {  // input row y = 64 b + 8 u + e; (y & 7) == e
+            w.csum = w.csum + in[e];
+            w.csum = w.csum - w.cring[e];
+            w.cring[e] = in[e];
+            if (e == 0 && (b > 0 || u > 0)) {
+                // y = 8 i + 8 entered: output row o = y - 4 = 8 i + 4, i = 8 b + u - 1; /8 for the window, /64 for the scale
+                store_B(w, 8 * b + u - 1, w.csum * (0.125f * 0.015625f));
+            }
+        }
+    }
+}
+
+// edge pre-pass: pass-1 values (x64) of columns 0,1,2,508,509,510 for V rows 64b .. 64b+63
+//   (FIRST: also consumes the chain's phase 1 = luma rows 0..3)
+__device__ __forceinline__ void edge_rowvals(const Wave &w, int y, bool live, float (&rv)[6])
+{
+    // lane = luma row y: R = horizontal clipped window sum of luma (exact), rowval x 64 = (64 R) / window
+    const int yc = y > 511 ? 511 : y;
+    const Px8 pl = load_px8(w.img + (size_t)yc * w.row_stride);
+    const Px8 pr = load_px8(w.img + (size_t)yc * w.row_stride + 504 * 3);
+    float l[8], r[8];
+    luma8(pl, l);
+    luma8(pr, r);
+    const float r0 = (((l[0] + l[1]) + l[2]) + l[3]) + l[4];
+    const float r1 = r0 + l[5];
+    const float r2 = r1 + l[6];
+    const float q510 = (((r[3] + r[4]) + r[5]) + r[6]) + r[7];
+    const float q509 = q510 + r[2];
+    const float q508 = q509 + r[1];
+    rv[0] = (r0 * 64.0f) / 5.0f;
+    rv[1] = (r1 * 64.0f) / 6.0f;
+    rv[2] = (r2 * 64.0f) / 7.0f;
+    rv[3] = (q508 * 64.0f) / 7.0f;
+    rv[4] = (q509 * 64.0f) / 6.0f;
+    rv[5] = (q510 * 64.0f) / 5.0f;
+    if (!live) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) rv[k] = 0.f;
+    }
+}
+
+__device__ __forceinline__ void edge_prologue(Wave &w)
+{
+    float *edge = reinterpret_cast<float *>(w.lds + OFF_EDGE);
+    float rv[6];
+    edge_rowvals(w, w.lane & 3, true, rv);
+    if (w.lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) edge[k * 64 + w.lane] = rv[k];
+    }
+    __syncthreads();
+    w.ecs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w.ering[i] = 0.f;
+    if (w.lane < 6) {  // phase 1 of the column box: accumulate rows 0..3, no output
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float v = edge[w.lane * 64 + t];
+            w.ecs = w.ecs + v;
+            w.ering[t] = v;
+        }
+    }
+    __syncthreads();
+}
+
+template <int KIND>  // 0 = first band, 1 = middle, 2 = last band
+__device__ __forceinline__ void edge_band(Wave &w, int b)
+{
+    float *edge = reinterpret_cast<float *>(w.lds + OFF_EDGE);
+    {
+        float rv[6];
+        const int y = 64 * b + 4 + w.lane;
+        edge_rowvals(w, y, y < 512, rv);
+#pragma unroll
+        for (int k = 0; k < 6; k++) edge[k * 64 + w.lane] = rv[k];
+    }
+    __syncthreads();
+    if (w.lane < 6) {
+        float *mine = edge + w.lane * 64;
+#pragma unroll 1
+        for (int u = 0; u < 8; u++) {
+            float in[8], out[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) in[e] = mine[8 * u + e];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                // chain input row y = 64b + 4 + 8u + e, ring slot (y & 7) = (e + 4) & 7, output row o = y - 4 = 64b + 8u + e
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int slot = (e + 4) & 7;
+                const bool add = !(KIND == 2 && u == 7 && e >= 4);  // y >= 512: phase 4, nothing enters
+                if (add) w.ecs = w.ecs + in[e];
+                w.ecs = w.ecs - w.ering[slot];
+                w.ering[slot] = in[e];
+                float o;
+                if (KIND == 0 && u == 0 && e < 3)
+                    o = w.ecs / (float)(5 + e);                       // o = 0,1,2: windows 5,6,7
+                else if (KIND == 2 && u == 7 && e >= 4)
+                    o = w.ecs / (float)(11 - e);                      // o = 508..511: windows 7,6,5,4
+                else
+                    o = w.ecs * 0.125f;
+                out[e] = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) mine[8 * u + e] = out[e];
+        }
+    }
+    __syncthreads();
+}
+
+template <int KIND>
+__device__ __forceinline__ void do_band(Wave &w, int b, Px8 (&pre)[8])
+{
+    constexpr bool EDGE_ROWS = KIND != 1;
+    edge_band<KIND>(w, b);
+    scan_reset(w, b);
+#pragma unroll 1
+    for (int s = 0; s < 8; s++) {
+        tile_build(w, b, s, pre);
+        if (s < 7)
+            tile_issue(w, b, s + 1, pre);
+        else if (b < 7)
+            tile_issue(w, b + 1, 0, pre);
+        if (s == 0)
+            scan_strip<EDGE_ROWS, true, false>(w, s);
+        else if (s == 7)
+            scan_strip<EDGE_ROWS, false, true>(w, s);
+        else
+            scan_strip<EDGE_ROWS, false, false>(w, s);
+        __syncthreads();
+        if (s == 3) col_pass(w, b, false);
+        if (s == 7) col_pass(w, b, true);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64) pdq_fused512_kernel(const uint8_t *__restrict__ px, uint32_t n, size_t row_stride,
+                                                          size_t image_stride, uint8_t *hash, float *quality, float *coeffs,
+                                                          uint8_t *dihedral, uint8_t *valid)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    const uint32_t img = blockIdx.x;
+    Wave w;
+    w.lds = lds;
+    w.img = px + (size_t)img * image_stride;
+    w.row_stride = row_stride;
+    w.lane = threadIdx.x;
+    w.csum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w.cring[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; i++) w.B[i] = 0.f;
+
+    // ---- prologue: luma rows 0..3 become the first band's history (rows -3..-1 are outside: zero)
+    {
+        const int c = w.lane & 7, g = w.lane >> 3;
+        for (int j = 0; j < 3; j++)
+            for (int t = w.lane; t < 64; t += 64) *reinterpret_cast<uint4 *>(lds + OFF_STATE + j * 1024 + t * 16) = make_uint4(0, 0, 0, 0);
+#pragma unroll 1
+        for (int it = 0; it < 4; it++) {
+            const int s = 2 * it + (g >> 2), row = g & 3;
+            const Px8 p = load_px8(w.img + (size_t)row * row_stride + (size_t)(64 * s + 8 * c) * 3);
+            *reinterpret_cast<uint4 *>(lds + OFF_STATE + (3 + row) * 1024 + (64 * s + 8 * c) * 2) = row_bits(pack_row(p, false));
+        }
+    }
+    edge_prologue(w);
+
+    Px8 pre[8];
+    tile_issue(w, 0, 0, pre);
+    do_band<0>(w, 0, pre);
+#pragma unroll 1
+    for (int b = 1; b < 7; b++) do_band<1>(w, b, pre);
+    do_band<2>(w, 7, pre);
+
+    // pass-2 column chain, phase 4 first step: out[508] = (csum - in[504]) / 7  (ring slot 0), unscale by 64
+    w.csum = w.csum - w.cring[0];
+    w.B[63] = (w.csum / 7.0f) * 0.015625f;
+
+    __syncthreads();
+    rph::pdq_tail(w.B, reinterpret_cast<float *>(lds), w.lane, hash + (size_t)img * 32, quality ? quality + img : nullptr,
+                  coeffs ? coeffs + (size_t)img * 256 : nullptr, dihedral ? dihedral + (size_t)img * 256 : nullptr);
+    if (valid && w.lane == 0) valid[img] = 1;
+}
+
+}  // namespace
+
+int rph_launch_pdq_fused512(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, size_t row_stride, size_t image_stride,
+                            uint8_t *d_hash, float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid,
+                            hipStream_t stream)
+{
+    (void)ctx;
+    if (n == 0) return RPH_OK;
+    hipLaunchKernelGGL(pdq_fused512_kernel, dim3(n), dim3(64), 0, stream, d_px, n, row_stride, image_stride, d_hash, d_quality,
+                       d_coeffs, d_dihedral, d_valid);
+    RPH_HIP_CHECK(hipGetLastError());
+    return RPH_OK;
 }

@@ -324,3 +324,86 @@ def test_one_million_hashes_threshold_32(eng, oracle):
     assert edge_set(edges) == sorted(want)
     special = [e for e in edges if e["d"] == 32 and (int(e["i"]), int(e["j"])) == (i, j)][0]
     assert not (special["flags"] & 0x8000)  # unreachable for find_groups' R<=1 probing
+
+
+# ------------------------------------------------------------------ fused 512x512 kernel
+def _fused_images():
+    rng = np.random.default_rng(2026)
+    yy, xx = np.mgrid[0:512, 0:512]
+    imgs = [rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)]
+    ramp = np.zeros((512, 512, 3), np.uint8)
+    ramp[..., 0] = (xx * 255) // 511
+    ramp[..., 1] = (yy * 255) // 511
+    ramp[..., 2] = ((xx + yy) * 255) // 1022
+    imgs.append(ramp)
+    imgs.append(np.repeat((((yy // 32 + xx // 32) % 2) * 255).astype(np.uint8)[..., None], 3, axis=2))
+    imgs.append(np.full((512, 512, 3), 255, np.uint8))      # saturated: largest running sums
+    imgs.append(np.full((512, 512, 3), 128, np.uint8))      # flat: quality 0, all coefficients tie
+    imgs.append(np.zeros((512, 512, 3), np.uint8))
+    tiny = rng.integers(0, 4, (512, 512, 3), dtype=np.uint8)  # tiny values next to a bright frame: finest f32 lattice
+    tiny[:, :8] = 255
+    tiny[:8, :] = 251
+    tiny[:, 505:] = 253
+    tiny[506:, :] = 249
+    imgs.append(tiny)
+    dots = np.zeros((512, 512, 3), np.uint8)
+    for (y, x) in [(3, 2), (509, 510), (255, 255), (0, 0), (511, 511), (0, 511), (511, 0), (4, 507), (60, 63), (64, 64), (447, 448)]:
+        dots[y, x] = 255
+    imgs.append(dots)
+    return np.stack(imgs)
+
+
+def test_fused512_kernel_matches_oracle_bit_for_bit(eng, oracle):
+    imgs = _fused_images()
+    eng.set_pdq_kernel(1)
+    out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
+    for k in range(len(imgs)):
+        rc, coeffs, q = oracle.pdq_features(imgs[k])
+        assert rc == 0 and out["valid"][k] == 1
+        assert np.array_equal(bits(out["coeffs"][k]), bits(coeffs)), f"coefficients differ for image {k}"
+        assert bits(out["quality"][k:k + 1])[0] == bits(np.float32(q))[()], k
+        assert np.array_equal(out["hash"][k], oracle.to_hash(coeffs)), k
+        assert np.array_equal(out["dihedral"][k], oracle.dihedral_hashes(coeffs)), k
+
+
+def test_fused512_on_synthetic_bench_images(eng, oracle):
+    """the bench workload itself: 24 images of the synthetic sequence (incl. a near-duplicate pair) vs the oracle"""
+    imgs = eng.synth_images(990, 24)
+    out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True)
+    ref_hash, ref_q, ref_c = oracle.pdq_batch_rgb(imgs, want_coeffs=True)
+    assert np.array_equal(out["hash"], ref_hash)
+    assert np.array_equal(bits(out["coeffs"]), bits(ref_c)) and np.array_equal(bits(out["quality"]), bits(ref_q))
+    assert oracle.hamming256(out["hash"][8], out["hash"][9]) <= 16      # k = 998 / 999: same blocks, different noise
+    assert (ref_q == 1.0).all()
+
+
+def test_fused512_equals_generic_on_4096_images(eng):
+    """full-size style check without the oracle: the two independent device paths agree on every hash, quality, coefficient"""
+    n = 4096
+    d_img = eng.dev_alloc(n * 512 * 512 * 3)
+    bufs = [eng.dev_alloc(n * 32), eng.dev_alloc(n * 4), eng.dev_alloc(n * 1024)]
+    res = []
+    try:
+        eng.synth_images_dev(d_img, 123_000, n)
+        for which in (1, 0):
+            eng.set_pdq_kernel(which)
+            for p, nb in zip(bufs, (n * 32, n * 4, n * 1024)):
+                eng.dev_memset(p, 0xEE, nb)
+            eng.pdq_hash_batch_dev(d_img, n, 512, 512, 3, bufs[0], d_quality=bufs[1], d_coeffs=bufs[2])
+            eng.synchronize()
+            h, q, c = np.zeros((n, 32), np.uint8), np.zeros(n, np.float32), np.zeros((n, 256), np.float32)
+            eng.dev_download(h, bufs[0]); eng.dev_download(q, bufs[1]); eng.dev_download(c, bufs[2])
+            res.append((h, q, c))
+    finally:
+        eng.set_pdq_kernel(1)
+        for p in [d_img] + bufs:
+            eng.dev_free(p)
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(bits(res[0][1]), bits(res[1][1])) and np.array_equal(bits(res[0][2]), bits(res[1][2]))
+    # every 1000-image stripe holds one known near-duplicate pair (k % 1000 == 999 shares blocks with k - 1)
+    from rupphash_amd import hamminghash as hh
+
+    h = res[0][0]
+    for k in range(123_000, 123_000 + n):
+        if k % 1000 == 999 and k - 1 >= 123_000:
+            assert hh.hamming_distance(h[k - 123_000], h[k - 1 - 123_000]) <= 16
