@@ -27,6 +27,18 @@ HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8.0 TB/s s
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6e12
 
 
+def usable_cores():
+    """threads for the CPU baseline: the affinity mask / cgroup quota, capped at the GPU box's per-GPU CPU share (16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("RPH_CPU_THREADS", "16"))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,7 +207,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle
 
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         # PDQ: the oracle on the first images of the same synthetic sequence, one image per task over all cores
         t_pilot, hp, _ = oracle.bench_pdq(img_sample[:cores], cores)
         per_img = max(t_pilot / cores, 1e-4)

@@ -130,13 +130,16 @@ struct Wave {
     int lane;
     // scan state (lane = row of the band), carried across the 8 strips of a band
     float hs, sum, ring[8];
-    h8 pv;
+    uint4 pv;  // previous octet of V (8 x f16)
     float row_d, row_dinv;  // pass-1 column-window divisor of this lane's row (8 except on the frame)
     // pass-2 column chain (lane = sampled column j), carried across the whole image
     float csum, cring[8];
     // edge chains (lanes 0..5), carried across the whole image
     float ecs, ering[8];
-    float B[64];
+    // B is produced 8 rows per band: Q[8 b + u] holds decimated row i = 8 b + u - 1 (Q[0] is a dummy);
+    // registers cannot be indexed by b, so each band's 8 values enter at the top and the file shifts down by 8
+    float Q[64];
+    float bnew[8];
 };
 
 __device__ __forceinline__ const uint8_t *tile_px(const Wave &w, int b, int s, int k, int c, int g, bool &beyond)
@@ -208,6 +211,29 @@ __device__ __forceinline__ void tile_build(Wave &w, int b, int s, const Px8 (&pr
     __syncthreads();
 }
 
+// hs +/- (f16 half of a packed dword): v_fma_mix_f32 reads the f16 operand directly (no v_cvt); the sums are
+// exact integers, so the fused form cannot differ from cvt + add
+template <int HI>
+__device__ __forceinline__ float hs_add(float hs, uint32_t packed)
+{
+    float r;
+    if (HI)
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(hs));
+    else
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(hs));
+    return r;
+}
+template <int HI>
+__device__ __forceinline__ float hs_sub(float hs, uint32_t packed)
+{
+    float r;
+    if (HI)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(hs));
+    else
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(hs));
+    return r;
+}
+
 // one step of the pass-2 row chain: input in2 (scaled by 64) enters, the input 8 back leaves
 template <int E>
 __device__ __forceinline__ void row_step(Wave &w, float in2)
@@ -234,9 +260,11 @@ __device__ __forceinline__ void scan_strip(Wave &w, int s)
     const uint8_t *tp = w.lds + OFF_TILE + r * TILE_PITCH;
     float *samp = reinterpret_cast<float *>(w.lds + OFF_SAMP) + r * SAMP_PITCH;
     const float *edge = reinterpret_cast<const float *>(w.lds + OFF_EDGE);
-#pragma unroll 1
+#pragma unroll
     for (int q = 0; q < 8; q++) {
-        const h8 cur = *reinterpret_cast<const h8 *>(tp + 16 * q);
+        const uint4 cur = *reinterpret_cast<const uint4 *>(tp + 16 * q);
+        const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
+        const uint32_t pw[4] = {w.pv.x, w.pv.y, w.pv.z, w.pv.w};
         const bool first_octet = FIRST && q == 0;
         float e0 = 0.f, e1 = 0.f, e2 = 0.f;
         if (first_octet) {  // pass-1 values of columns 0,1,2 come from the edge chains
@@ -246,8 +274,8 @@ __device__ __forceinline__ void scan_strip(Wave &w, int s)
         }
 #define RPH_STEP(E)                                                              \
     {                                                                            \
-        w.hs = w.hs + (float)cur[E];                                             \
-        w.hs = w.hs - (float)w.pv[E];                                            \
+        w.hs = hs_add<(E) & 1>(w.hs, cw[(E) >> 1]);                              \
+        w.hs = hs_sub<(E) & 1>(w.hs, pw[(E) >> 1]);                              \
         float in2 = pass1_value<EDGE_ROWS>(w, w.hs);                             \
         if (first_octet && (E) == 4) in2 = e0;                                   \
         if (first_octet && (E) == 5) in2 = e1;                                   \
@@ -267,10 +295,10 @@ __device__ __forceinline__ void scan_strip(Wave &w, int s)
     if (LAST) {
         // columns 508..511: V beyond the image is 0; 508,509,510 come from the edge chains, 511 has a 4-wide window
         const float e3 = edge[3 * 64 + r], e4 = edge[4 * 64 + r], e5 = edge[5 * 64 + r];
-        w.hs = w.hs - (float)w.pv[0]; row_step<0>(w, e3);
-        w.hs = w.hs - (float)w.pv[1]; row_step<1>(w, e4);
-        w.hs = w.hs - (float)w.pv[2]; row_step<2>(w, e5);
-        w.hs = w.hs - (float)w.pv[3];
+        w.hs = hs_sub<0>(w.hs, w.pv.x); row_step<0>(w, e3);
+        w.hs = hs_sub<1>(w.hs, w.pv.x); row_step<1>(w, e4);
+        w.hs = hs_sub<0>(w.hs, w.pv.y); row_step<2>(w, e5);
+        w.hs = hs_sub<1>(w.hs, w.pv.y);
         {
             const float in511 = EDGE_ROWS ? div_small(w.hs * 16.0f, w.row_d, w.row_dinv) : w.hs * 2.0f;
             row_step<3>(w, in511);
@@ -287,7 +315,7 @@ __device__ __forceinline__ void scan_reset(Wave &w, int b)
     w.sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) w.ring[i] = 0.f;
-    w.pv = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    w.pv = make_uint4(0, 0, 0, 0);
     // column-window size of row y = 64 b + lane: 5,6,7,8 | 8 ... | 7,6,5,4
     const int y = 64 * b + w.lane;
     const int lo = y - 3 < 0 ? 0 : y - 3, hi = y + 4 > 511 ? 511 : y + 4;
@@ -296,32 +324,13 @@ __device__ __forceinline__ void scan_reset(Wave &w, int b)
     w.row_dinv = 1.0f / d;
 }
 
-// store B[i] with a wave-uniform runtime i (registers cannot be indexed dynamically)
-__device__ __forceinline__ void store_B(Wave &w, int i, float v)
-{
-#define RPH_CASE8(base)                                                   \
-    case (base) + 0: w.B[(base) + 0] = v; break;                          \
-    case (base) + 1: w.B[(base) + 1] = v; break;                          \
-    case (base) + 2: w.B[(base) + 2] = v; break;                          \
-    case (base) + 3: w.B[(base) + 3] = v; break;                          \
-    case (base) + 4: w.B[(base) + 4] = v; break;                          \
-    case (base) + 5: w.B[(base) + 5] = v; break;                          \
-    case (base) + 6: w.B[(base) + 6] = v; break;                          \
-    case (base) + 7: w.B[(base) + 7] = v; break;
-    switch (i) {
-        RPH_CASE8(0) RPH_CASE8(8) RPH_CASE8(16) RPH_CASE8(24) RPH_CASE8(32) RPH_CASE8(40) RPH_CASE8(48) RPH_CASE8(56)
-        default: break;
-    }
-#undef RPH_CASE8
-}
-
 // pass-2 column chain over the 64 rows of band b for the sampled columns of one half (lanes [0,31) or [31,64))
 __device__ __forceinline__ void col_pass(Wave &w, int b, bool second_half)
 {
     const bool active = second_half ? (w.lane >= 31) : (w.lane < 31);
     if (!active) return;
     const float *samp = reinterpret_cast<const float *>(w.lds + OFF_SAMP) + (second_half ? w.lane - 31 : w.lane);
-#pragma unroll 1
+#pragma unroll
     for (int u = 0; u < 8; u++) {
         float in[8];
 #pragma unroll
@@ -333,7 +342,7 @@ __device__ __forceinline__ void col_pass(Wave &w, int b, bool second_half)
             w.cring[e] = in[e];
             if (e == 0 && (b > 0 || u > 0)) {
                 // y = 8 i + 8 entered: output row o = y - 4 = 8 i + 4, i = 8 b + u - 1; /8 for the window, /64 for the scale
-                store_B(w, 8 * b + u - 1, w.csum * (0.125f * 0.015625f));
+                w.bnew[u] = w.csum * (0.125f * 0.015625f);
             }
         }
     }
@@ -461,6 +470,10 @@ __device__ __forceinline__ void do_band(Wave &w, int b, Px8 (&pre)[8])
         if (s == 7) col_pass(w, b, true);
         __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < 56; i++) w.Q[i] = w.Q[i + 8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) w.Q[56 + u] = w.bnew[u];
 }
 
 __global__ void __launch_bounds__(64) pdq_fused512_kernel(const uint8_t *__restrict__ px, uint32_t n, size_t row_stride,
@@ -478,7 +491,9 @@ __global__ void __launch_bounds__(64) pdq_fused512_kernel(const uint8_t *__restr
 #pragma unroll
     for (int i = 0; i < 8; i++) w.cring[i] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 64; i++) w.B[i] = 0.f;
+    for (int i = 0; i < 64; i++) w.Q[i] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; u++) w.bnew[u] = 0.f;
 
     // ---- prologue: luma rows 0..3 become the first band's history (rows -3..-1 are outside: zero)
     {
@@ -503,10 +518,13 @@ __global__ void __launch_bounds__(64) pdq_fused512_kernel(const uint8_t *__restr
 
     // pass-2 column chain, phase 4 first step: out[508] = (csum - in[504]) / 7  (ring slot 0), unscale by 64
     w.csum = w.csum - w.cring[0];
-    w.B[63] = (w.csum / 7.0f) * 0.015625f;
+    float B[64];
+#pragma unroll
+    for (int i = 0; i < 63; i++) B[i] = w.Q[i + 1];
+    B[63] = (w.csum / 7.0f) * 0.015625f;
 
     __syncthreads();
-    rph::pdq_tail(w.B, reinterpret_cast<float *>(lds), w.lane, hash + (size_t)img * 32, quality ? quality + img : nullptr,
+    rph::pdq_tail(B, reinterpret_cast<float *>(lds), w.lane, hash + (size_t)img * 32, quality ? quality + img : nullptr,
                   coeffs ? coeffs + (size_t)img * 256 : nullptr, dihedral ? dihedral + (size_t)img * 256 : nullptr);
     if (valid && w.lane == 0) valid[img] = 1;
 }
