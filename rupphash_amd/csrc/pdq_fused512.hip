@@ -34,10 +34,10 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr int TILE_PITCH = 144;                 // bytes per V-tile row: 64 f16 + 16 B pad (conflict-free b128 reads, lane = row)
 constexpr int OFF_TILE = 0;                     // 64 * 144 = 9216 B; the exchange area and the tail scratch alias it
 constexpr int OFF_STATE = 9216;                 // 7 luma rows x 512 columns, f16 = 7168 B
-constexpr int OFF_SAMP = OFF_STATE + 7168;      // 64 rows x 33 floats = 8448 B
-constexpr int SAMP_PITCH = 33;
-constexpr int OFF_EDGE = OFF_SAMP + 8448;       // 6 chains x 64 rows x f32 = 1536 B (rv in, edge values out, in place)
-constexpr int LDS_BYTES = OFF_EDGE + 1536;      // 26368 B -> 6 waves per CU
+constexpr int SAMP_PITCH = 33;                  // sample transpose buffer: 64 rows x 33 floats = 8448 B, aliases the dead V tile
+constexpr int OFF_EDGE = OFF_STATE + 7168;      // 6 chains x 64 rows x f32 = 1536 B (rv in, edge values out, in place)
+constexpr int LDS_BYTES = OFF_EDGE + 1536;      // 17920 B -> 9 waves per CU
+static_assert(64 * SAMP_PITCH * 4 <= 9216, "sample transpose buffer must fit in the dead V tile");
 static_assert(rph::TAIL_LDS_FLOATS * 4 <= 9216, "tail scratch must fit in the dead V tile");
 
 struct Px8 {  // 8 RGB pixels = 24 bytes = 6 dwords, loaded as 2 x dwordx3
@@ -120,6 +120,12 @@ __device__ __forceinline__ float div_small(float N, float d, float dinv)
     return __builtin_fmaf(r, dinv, q0);
 }
 
+// Phase separator inside the wave.  The workgroup IS one wave and the LDS executes a wave's DS instructions in
+// issue order, so a later ds_read sees an earlier ds_write of any lane without waiting; all that is needed is
+// that the compiler keeps the program order.  (__syncthreads() would also drain vmcnt and so serialise the
+// prefetched global loads of the next tile behind every phase.)
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
+
 // ---------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------
@@ -132,14 +138,18 @@ struct Wave {
     float hs, sum, ring[8];
     uint4 pv;  // previous octet of V (8 x f16)
     float row_d, row_dinv;  // pass-1 column-window divisor of this lane's row (8 except on the frame)
+    // pass-2 row outputs at the sampled columns of the current half band (lane = row): 8 enter per strip at the
+    // top and the file shifts down by 8, so after 4 strips smp[t] is sample slot t of the half band
+    float smp[32];
+    float smp_last;  // out[508] (sample 63), produced by the last strip's epilogue
     // pass-2 column chain (lane = sampled column j), carried across the whole image
     float csum, cring[8];
     // edge chains (lanes 0..5), carried across the whole image
     float ecs, ering[8];
-    // B is produced 8 rows per band: Q[8 b + u] holds decimated row i = 8 b + u - 1 (Q[0] is a dummy);
-    // registers cannot be indexed by b, so each band's 8 values enter at the top and the file shifts down by 8
-    float Q[64];
+    // rows of the decimated buffer produced by the current band (lane = column), fed to the streaming tail
     float bnew[8];
+    rph::TailAcc tail;
+    bool want_quality;
 };
 
 __device__ __forceinline__ const uint8_t *tile_px(const Wave &w, int b, int s, int k, int c, int g, bool &beyond)
@@ -161,15 +171,21 @@ __device__ __forceinline__ void tile_issue(const Wave &w, int b, int s, Px8 (&pr
     }
 }
 
-// LOAD phase 2: luma, exchange of the 7 rows above, vertical window sums, V tile
-__device__ __forceinline__ void tile_build(Wave &w, int b, int s, const Px8 (&pre)[8])
+// LOAD phase 2a: luma of the 8 prefetched rows (frees the prefetch registers for the next tile's loads)
+template <bool LAST_BAND>
+__device__ __forceinline__ void tile_luma(const Wave &w, int b, const Px8 (&pre)[8], Row8 (&L)[8])
+{
+    const int g = w.lane >> 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) L[k] = pack_row(pre[k], LAST_BAND && (64 * b + 4 + 8 * g + k >= 512));
+}
+
+// LOAD phase 2b: exchange of the 7 rows above, vertical window sums, V tile
+__device__ __forceinline__ void tile_build(Wave &w, int s, const Row8 (&L)[8])
 {
     const int c = w.lane & 7, g = w.lane >> 3;
     uint8_t *tile = w.lds + OFF_TILE;
     uint8_t *state = w.lds + OFF_STATE + (64 * s + 8 * c) * 2;
-    Row8 L[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) L[k] = pack_row(pre[k], 64 * b + 4 + 8 * g + k >= 512);
 
     // publish rows 1..7 for the lane below (g + 1); the tile is dead here (its scan is over)
     if (g < 7) {
@@ -177,7 +193,7 @@ __device__ __forceinline__ void tile_build(Wave &w, int b, int s, const Px8 (&pr
 #pragma unroll
         for (int k = 1; k < 8; k++) *reinterpret_cast<uint4 *>(x + (k - 1) * 128) = row_bits(L[k]);
     }
-    __syncthreads();
+    wave_lds_fence();
     // the 7 luma rows above this lane's first row: from lane g-1, or for g == 0 from the previous band
     Row8 hist[7];
     {
@@ -186,7 +202,7 @@ __device__ __forceinline__ void tile_build(Wave &w, int b, int s, const Px8 (&pr
 #pragma unroll
         for (int j = 0; j < 7; j++) hist[j] = bits_row(*reinterpret_cast<const uint4 *>(hp + j * stride));
     }
-    __syncthreads();
+    wave_lds_fence();
     if (g == 7) {  // rows 1..7 of the last lane group are the next band's history for these columns
 #pragma unroll
         for (int k = 1; k < 8; k++) *reinterpret_cast<uint4 *>(state + (k - 1) * 1024) = row_bits(L[k]);
@@ -208,7 +224,7 @@ __device__ __forceinline__ void tile_build(Wave &w, int b, int s, const Px8 (&pr
         for (int i = 0; i < 4; i++) v.q[i] = (v.q[i] - hist[m - 1].q[i]) + L[m].q[i];  // subtract first: stays <= 2040
         *reinterpret_cast<uint4 *>(tile + (8 * g + m) * TILE_PITCH + 16 * c) = row_bits(v);
     }
-    __syncthreads();
+    wave_lds_fence();
 }
 
 // hs +/- (f16 half of a packed dword): v_fma_mix_f32 reads the f16 operand directly (no v_cvt); the sums are
@@ -254,12 +270,12 @@ __device__ __forceinline__ float pass1_value(const Wave &w, float hs)
 
 // SCAN of strip s of the current band.  FIRST/LAST: strip 0 / strip 7 (frame columns).
 template <bool EDGE_ROWS, bool FIRST, bool LAST>
-__device__ __forceinline__ void scan_strip(Wave &w, int s)
+__device__ __forceinline__ void scan_strip(Wave &w)
 {
     const int r = w.lane;
     const uint8_t *tp = w.lds + OFF_TILE + r * TILE_PITCH;
-    float *samp = reinterpret_cast<float *>(w.lds + OFF_SAMP) + r * SAMP_PITCH;
     const float *edge = reinterpret_cast<const float *>(w.lds + OFF_EDGE);
+    float fresh[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const uint4 cur = *reinterpret_cast<const uint4 *>(tp + 16 * q);
@@ -284,10 +300,7 @@ __device__ __forceinline__ void scan_strip(Wave &w, int s)
     }
         RPH_STEP(0) RPH_STEP(1) RPH_STEP(2) RPH_STEP(3) RPH_STEP(4)
         // output o = xv - 8 = 8j + 4 right after element 4 of octet j + 1
-        if (!first_octet) {
-            const int j = 8 * s + q - 1;
-            samp[j < 31 ? j : j - 31] = w.sum * 0.125f;
-        }
+        fresh[q] = w.sum * 0.125f;  // sample slot 8 s + q (slot 0 of the image = octet 0 is a dummy)
         RPH_STEP(5) RPH_STEP(6) RPH_STEP(7)
 #undef RPH_STEP
         w.pv = cur;
@@ -305,8 +318,12 @@ __device__ __forceinline__ void scan_strip(Wave &w, int s)
         }
         // phase 4, first step: out[508] = (sum - in[504]) / 7   (ring slot of ri = 504 is 0)
         w.sum = w.sum - w.ring[0];
-        samp[63 - 31] = w.sum / 7.0f;
+        w.smp_last = w.sum / 7.0f;
     }
+#pragma unroll
+    for (int i = 0; i < 24; i++) w.smp[i] = w.smp[i + 8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) w.smp[24 + q] = fresh[q];
 }
 
 __device__ __forceinline__ void scan_reset(Wave &w, int b)
@@ -324,28 +341,36 @@ __device__ __forceinline__ void scan_reset(Wave &w, int b)
     w.row_dinv = 1.0f / d;
 }
 
-// pass-2 column chain over the 64 rows of band b for the sampled columns of one half (lanes [0,31) or [31,64))
+// pass-2 column chain over the 64 rows of band b for the sampled columns of one half band.
+// First half: sample slots 0..31 = [dummy, j = 0..30] -> lanes j = 0..30 read slot j + 1.
+// Second half: slots 0..31 = j = 31..62, slot 32 = j = 63      -> lanes j = 31..63 read slot j - 31.
 __device__ __forceinline__ void col_pass(Wave &w, int b, bool second_half)
 {
+    // transpose through the V tile, which is dead between the last scan of the half band and the next tile build
+    float *tb = reinterpret_cast<float *>(w.lds + OFF_TILE);
+#pragma unroll
+    for (int t = 0; t < 32; t++) tb[w.lane * SAMP_PITCH + t] = w.smp[t];
+    tb[w.lane * SAMP_PITCH + 32] = w.smp_last;
+    wave_lds_fence();
     const bool active = second_half ? (w.lane >= 31) : (w.lane < 31);
-    if (!active) return;
-    const float *samp = reinterpret_cast<const float *>(w.lds + OFF_SAMP) + (second_half ? w.lane - 31 : w.lane);
+    if (active) {
+        const float *samp = tb + (second_half ? w.lane - 31 : w.lane + 1);
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        float in[8];
+        for (int u = 0; u < 8; u++) {
+            float in[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) in[e] = samp[(8 * u + e) * SAMP_PITCH];
+            for (int e = 0; e < 8; e++) in[e] = samp[(8 * u + e) * SAMP_PITCH];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {  // input row y = 64 b + 8 u + e; (y & 7) == e
-            w.csum = w.csum + in[e];
-            w.csum = w.csum - w.cring[e];
-            w.cring[e] = in[e];
-            if (e == 0 && (b > 0 || u > 0)) {
+            for (int e = 0; e < 8; e++) {  // input row y = 64 b + 8 u + e; (y & 7) == e
+                w.csum = w.csum + in[e];
+                w.csum = w.csum - w.cring[e];
+                w.cring[e] = in[e];
                 // y = 8 i + 8 entered: output row o = y - 4 = 8 i + 4, i = 8 b + u - 1; /8 for the window, /64 for the scale
-                w.bnew[u] = w.csum * (0.125f * 0.015625f);
+                if (e == 0) w.bnew[u] = w.csum * (0.125f * 0.015625f);
             }
         }
     }
+    wave_lds_fence();
 }
 
 // edge pre-pass: pass-1 values (x64) of columns 0,1,2,508,509,510 for V rows 64b .. 64b+63
@@ -386,7 +411,7 @@ __device__ __forceinline__ void edge_prologue(Wave &w)
 #pragma unroll
         for (int k = 0; k < 6; k++) edge[k * 64 + w.lane] = rv[k];
     }
-    __syncthreads();
+    wave_lds_fence();
     w.ecs = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) w.ering[i] = 0.f;
@@ -398,7 +423,7 @@ __device__ __forceinline__ void edge_prologue(Wave &w)
             w.ering[t] = v;
         }
     }
-    __syncthreads();
+    wave_lds_fence();
 }
 
 template <int KIND>  // 0 = first band, 1 = middle, 2 = last band
@@ -412,7 +437,7 @@ __device__ __forceinline__ void edge_band(Wave &w, int b)
 #pragma unroll
         for (int k = 0; k < 6; k++) edge[k * 64 + w.lane] = rv[k];
     }
-    __syncthreads();
+    wave_lds_fence();
     if (w.lane < 6) {
         float *mine = edge + w.lane * 64;
 #pragma unroll 1
@@ -443,7 +468,7 @@ __device__ __forceinline__ void edge_band(Wave &w, int b)
             for (int e = 0; e < 8; e++) mine[8 * u + e] = out[e];
         }
     }
-    __syncthreads();
+    wave_lds_fence();
 }
 
 template <int KIND>
@@ -454,29 +479,31 @@ __device__ __forceinline__ void do_band(Wave &w, int b, Px8 (&pre)[8])
     scan_reset(w, b);
 #pragma unroll 1
     for (int s = 0; s < 8; s++) {
-        tile_build(w, b, s, pre);
+        Row8 L[8];
+        tile_luma<KIND == 2>(w, b, pre, L);
         if (s < 7)
             tile_issue(w, b, s + 1, pre);
         else if (b < 7)
             tile_issue(w, b + 1, 0, pre);
+        tile_build(w, s, L);
         if (s == 0)
-            scan_strip<EDGE_ROWS, true, false>(w, s);
+            scan_strip<EDGE_ROWS, true, false>(w);
         else if (s == 7)
-            scan_strip<EDGE_ROWS, false, true>(w, s);
+            scan_strip<EDGE_ROWS, false, true>(w);
         else
-            scan_strip<EDGE_ROWS, false, false>(w, s);
-        __syncthreads();
+            scan_strip<EDGE_ROWS, false, false>(w);
+        wave_lds_fence();
         if (s == 3) col_pass(w, b, false);
         if (s == 7) col_pass(w, b, true);
-        __syncthreads();
+        wave_lds_fence();
     }
+    // band b completed decimated rows i = 8 b + u - 1 (u = 0 of band 0 is a dummy): feed them to the tail in order
 #pragma unroll
-    for (int i = 0; i < 56; i++) w.Q[i] = w.Q[i + 8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) w.Q[56 + u] = w.bnew[u];
+    for (int u = 0; u < 8; u++)
+        if (KIND != 0 || u > 0) rph::tail_row(w.tail, w.bnew[u], 8 * b + u - 1, w.lane, w.want_quality);
 }
 
-__global__ void __launch_bounds__(64) pdq_fused512_kernel(const uint8_t *__restrict__ px, uint32_t n, size_t row_stride,
+__global__ void __launch_bounds__(64, 2) pdq_fused512_kernel(const uint8_t *__restrict__ px, uint32_t n, size_t row_stride,
                                                           size_t image_stride, uint8_t *hash, float *quality, float *coeffs,
                                                           uint8_t *dihedral, uint8_t *valid)
 {
@@ -488,10 +515,13 @@ __global__ void __launch_bounds__(64) pdq_fused512_kernel(const uint8_t *__restr
     w.row_stride = row_stride;
     w.lane = threadIdx.x;
     w.csum = 0.f;
+    w.smp_last = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; i++) w.smp[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) w.cring[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 64; i++) w.Q[i] = 0.f;
+    rph::tail_init(w.tail);
+    w.want_quality = quality != nullptr;
 #pragma unroll
     for (int u = 0; u < 8; u++) w.bnew[u] = 0.f;
 
@@ -518,13 +548,10 @@ __global__ void __launch_bounds__(64) pdq_fused512_kernel(const uint8_t *__restr
 
     // pass-2 column chain, phase 4 first step: out[508] = (csum - in[504]) / 7  (ring slot 0), unscale by 64
     w.csum = w.csum - w.cring[0];
-    float B[64];
-#pragma unroll
-    for (int i = 0; i < 63; i++) B[i] = w.Q[i + 1];
-    B[63] = (w.csum / 7.0f) * 0.015625f;
+    rph::tail_row(w.tail, (w.csum / 7.0f) * 0.015625f, 63, w.lane, w.want_quality);
 
     __syncthreads();
-    rph::pdq_tail(B, reinterpret_cast<float *>(lds), w.lane, hash + (size_t)img * 32, quality ? quality + img : nullptr,
+    rph::tail_finish(w.tail, reinterpret_cast<float *>(lds), w.lane, hash + (size_t)img * 32, quality ? quality + img : nullptr,
                   coeffs ? coeffs + (size_t)img * 256 : nullptr, dihedral ? dihedral + (size_t)img * 256 : nullptr);
     if (valid && w.lane == 0) valid[img] = 1;
 }

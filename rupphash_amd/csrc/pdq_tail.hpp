@@ -134,46 +134,61 @@ __device__ __forceinline__ void hashes_from_coeffs(const float (&c)[4], float *l
     emit_hash(tnb, med_nb, dihedral + 7 * 32, lane);  // transpose(neg_both)   anti-transpose
 }
 
-// Full tail.  lds: TAIL_LDS_FLOATS floats private to this wave.  Outputs are per-image pointers (nullable).
-__device__ __forceinline__ void pdq_tail(const float (&b)[64], float *lds, int lane, uint8_t *hash32, float *quality,
-                                         float *coeffs, uint8_t *dihedral)
+// ---------------------------------------------------------------------------------------------
+// Streaming form of the tail: rows of the decimated buffer are fed in ascending order k = 0..63
+// (lane j passes B[k][j]).  DCT pass 1 accumulates T[i][j] += D[i][k] * B[k][j] -- exactly the reference's
+// order over k -- so the 64x64 buffer never has to be resident; the quality metric is a sum of exact
+// integers and is accumulated on the fly.
+// ---------------------------------------------------------------------------------------------
+struct TailAcc {
+    float t[16];
+    float qsum;
+    float prev;  // previous row, for the vertical gradient
+};
+
+__device__ __forceinline__ void tail_init(TailAcc &a)
 {
-    // ---- quality: sum of trunc(|(a - b) * 100 / 255|) over vertical then horizontal neighbours.
-    // Every term is an integer <= 100 and there are 8064 of them, so the f32 sum is exact in any order.
+#pragma unroll
+    for (int i = 0; i < 16; i++) a.t[i] = 0.0f;
+    a.qsum = 0.0f;
+    a.prev = 0.0f;
+}
+
+// k is wave-uniform (compile-time or an SGPR): the 16 coefficients of column k come in one scalar load
+__device__ __forceinline__ void tail_row(TailAcc &a, float brow, int k, int lane, bool want_quality)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float p = __uint_as_float(c_dct_t.v[k * 16 + i]) * brow;
+        a.t[i] = a.t[i] + p;
+    }
+    if (want_quality) {
+        // trunc(|(a - b) * 100 / 255|) over vertical (row k-1 vs k) and horizontal (lane j vs j+1) neighbours
+        const float right = __shfl_down(brow, 1);
+        const float gh = truncf(fabsf(((brow - right) * 100.0f) / 255.0f));
+        const float gv = truncf(fabsf(((a.prev - brow) * 100.0f) / 255.0f));
+        a.qsum += (lane < 63) ? gh : 0.0f;
+        a.qsum += (k > 0) ? gv : 0.0f;
+    }
+    a.prev = brow;
+}
+
+// lds: TAIL_LDS_FLOATS floats private to this wave.  Outputs are per-image pointers (nullable).
+__device__ __forceinline__ void tail_finish(TailAcc &a, float *lds, int lane, uint8_t *hash32, float *quality, float *coeffs,
+                                            uint8_t *dihedral)
+{
     if (quality) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 63; i++) acc += truncf(fabsf(((b[i] - b[i + 1]) * 100.0f) / 255.0f));
-#pragma unroll
-        for (int i = 0; i < 64; i++) {
-            const float right = __shfl_down(b[i], 1);
-            const float g = truncf(fabsf(((b[i] - right) * 100.0f) / 255.0f));
-            acc += (lane < 63) ? g : 0.0f;
-        }
+        float acc = a.qsum;  // every term is an integer <= 100, 8064 terms: exact in f32 in any order
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         const float q = acc / 90.0f;
         if (lane == 0) *quality = q > 1.0f ? 1.0f : q;
     }
-
-    // ---- DCT pass 1: T[i][j] = sum_k D[i][k] * B[k][j], k ascending, accumulator from 0.0
-    float t[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) t[i] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 64; k++) {
-        const float bk = b[k];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const float p = __uint_as_float(c_dct_t.v[k * 16 + i]) * bk;
-            t[i] = t[i] + p;
-        }
-    }
     float *lds_t = lds;            // [16][65]
     float *lds_c = lds + 16 * 65;  // [256]
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; i++) lds_t[i * 65 + lane] = t[i];
+    for (int i = 0; i < 16; i++) lds_t[i * 65 + lane] = a.t[i];
     __syncthreads();
 
     // ---- DCT pass 2: C[i][j] = sum_k T[i][k] * D[j][k]; this lane: j = lane & 15, i = (lane >> 4) + 4m
@@ -193,6 +208,17 @@ __device__ __forceinline__ void pdq_tail(const float (&b)[64], float *lds, int l
         for (int m = 0; m < 4; m++) coeffs[lane + 64 * m] = c[m];
     }
     hashes_from_coeffs(c, lds_c, lane, hash32, dihedral);
+}
+
+// Whole-buffer form (generic path): lane j holds column j of the 64x64 buffer in registers.
+__device__ __forceinline__ void pdq_tail(const float (&b)[64], float *lds, int lane, uint8_t *hash32, float *quality,
+                                         float *coeffs, uint8_t *dihedral)
+{
+    TailAcc a;
+    tail_init(a);
+#pragma unroll
+    for (int k = 0; k < 64; k++) tail_row(a, b[k], k, lane, quality != nullptr);
+    tail_finish(a, lds, lane, hash32, quality, coeffs, dihedral);
 }
 
 }  // namespace rph
