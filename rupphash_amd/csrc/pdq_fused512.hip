@@ -76,14 +76,39 @@ __device__ __forceinline__ void luma8(const Px8 &v, float (&l)[8])
     l[4] = luma_px<4>(v); l[5] = luma_px<5>(v); l[6] = luma_px<6>(v); l[7] = luma_px<7>(v);
 }
 
-// 8 lumas -> 4 packed f16 pairs (integers <= 255: exact under any rounding mode)
+// 8 pixels -> 4 packed f16 luma pairs.
+// Bytes become f16 without a conversion: v_perm_b32 pairs each byte with the constant 0x64, and 0x6400 | v is
+// the f16 number 1024 + v.  v_dot2_f32_f16 then forms 299 r + 587 g + 114 b (+ the bias 1024 * 1000, removed by
+// the accumulator constant) with f32 accumulation: all products and sums are integers < 2^24, hence exact.
 struct Row8 {
     h2 q[4];
 };
+__device__ __forceinline__ h2 h2_bits(uint32_t u) { return __builtin_bit_cast(h2, u); }
+__device__ __forceinline__ h2 byte_pair_lo(uint32_t d) { return h2_bits(__builtin_amdgcn_perm(0x64646464u, d, 0x04010400u)); }
+__device__ __forceinline__ h2 byte_pair_hi(uint32_t d) { return h2_bits(__builtin_amdgcn_perm(0x64646464u, d, 0x04030402u)); }
+
 __device__ __forceinline__ Row8 pack_row(const Px8 &v, bool zero)
 {
+    // byte stream r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3 | ... : pair p holds bytes 2p, 2p+1
+    h2 P[12];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        P[2 * i] = byte_pair_lo(v.d[i]);
+        P[2 * i + 1] = byte_pair_hi(v.d[i]);
+    }
+    const h2 k_rg = h2{(_Float16)299.0f, (_Float16)587.0f};   // (r, g)
+    const h2 k_b0 = h2{(_Float16)114.0f, (_Float16)0.0f};      // (b, next r)
+    const h2 k_0r = h2{(_Float16)0.0f, (_Float16)299.0f};      // (prev b, r)
+    const h2 k_gb = h2{(_Float16)587.0f, (_Float16)114.0f};    // (g, b)
+    const float bias = 500.0f - 1024.0f * 1000.0f;
     float l[8];
-    luma8(v, l);
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {  // two pixels = 6 bytes = pairs 3pp, 3pp+1, 3pp+2
+        const float n0 = __builtin_amdgcn_fdot2(P[3 * pp], k_rg, __builtin_amdgcn_fdot2(P[3 * pp + 1], k_b0, bias, false), false);
+        const float n1 = __builtin_amdgcn_fdot2(P[3 * pp + 1], k_0r, __builtin_amdgcn_fdot2(P[3 * pp + 2], k_gb, bias, false), false);
+        l[2 * pp] = __builtin_truncf(n0 * 0.001f);
+        l[2 * pp + 1] = __builtin_truncf(n1 * 0.001f);
+    }
     Row8 r;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
