@@ -1,6 +1,6 @@
 // synth_kernels.hip -- device generators for the synthetic workloads of SURVEY.md 8(d).
-// Integer-only, counter based: the same functions as oracle/synth_ref.c state on the CPU
-// (tests compare them byte for byte), so benchmark inputs never cross PCIe.
+// Integer-only, counter based; the test suite holds an independent CPU statement of the same functions
+// and compares byte for byte, so benchmark inputs never cross PCIe.
 #include "rph_internal.h"
 
 namespace {
