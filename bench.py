@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--hashes", type=int, default=1_000_000, help="hashes at N=1 (scaled by sqrt(N))")
     ap.add_argument("--threshold", type=int, default=32)
     ap.add_argument("--hamming-steps", type=int, default=0, help="default: same as --steps")
-    ap.add_argument("--pdq-kernel", type=int, default=1, help="1 = fused 512x512 kernel, 0 = generic multi-pass")
+    ap.add_argument("--pdq-kernel", type=int, default=1, help="1 = fused, 64-px strips (default), 2 = fused, 128-px strips, 0 = generic multi-pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline leg")
     args = ap.parse_args()
@@ -187,7 +187,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"batch PDQ hash of {n_img} synthetic 512x512 RGB8 images per GPU, resident in HBM "
                                "(BASELINE config 2), hash-only output",
-                   "images_per_gpu": n_img, "image": "512x512x3 u8", "pdq_kernel": "fused512" if args.pdq_kernel else "generic",
+                   "images_per_gpu": n_img, "image": "512x512x3 u8", "pdq_kernel": {0: "generic", 1: "fused512/strip64", 2: "fused512/strip128"}[args.pdq_kernel],
                    "hash_checksum": hash_checksum},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,

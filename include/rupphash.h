@@ -101,8 +101,9 @@ int rph_pdq_hashes_from_coeffs(rph_ctx *ctx, const float *coeffs, uint32_t n, ui
 int rph_pdq_hashes_from_coeffs_dev(rph_ctx *ctx, const void *d_coeffs, uint32_t n, void *d_hash32,
                                    void *d_dihedral, void *stream);
 
-/* Which PDQ kernel a context uses for 512x512 RGB8: 0 = generic multi-pass
- * (any geometry), 1 = fused single-pass (default for 512x512x3).  Debug/bench. */
+/* Which PDQ kernel a context uses for 512x512 RGB8: 0 = generic multi-pass (any geometry), 1 = fused single-pass
+ * with 64-px strips (default: 8 waves per CU, fastest), 2 = fused with 128-px strips (cache-line aligned loads,
+ * 6 waves per CU).  All three produce identical bits.  Debug/bench. */
 int rph_pdq_set_kernel(rph_ctx *ctx, int which);
 
 /* calculate_target_dimensions (pdqhash.rs:224-235): integer geometry, host. */

@@ -5,11 +5,12 @@
 // The image is read from HBM exactly once (786 432 B); nothing but the outputs is written back.
 //
 // One wave (64 lanes) owns one image and never synchronises with another wave.  It walks the image
-// in 8 bands of 64 rows x 8 strips of 64 columns.  Per (band, strip) tile:
-//   LOAD   lane (c, g) = 8 columns x 8 rows: two global_load_dwordx3 per row, Rec.601 luma in f32
-//          (exact integers), packed to f16; the 7 luma rows above come from the lane with g-1
-//          through LDS (or from the previous band's saved rows), and the vertical 8-row window sums
-//          V (<= 2040, exact in f16) go to a 64x64 f16 tile in LDS.
+// in 8 bands of 64 rows x 4 strips of 128 columns (128 px = 384 B = exactly three 128-B cache lines, so
+// no line is ever requested by two tiles).  Per (band, strip) tile:
+//   LOAD   two half tiles of 32 rows; lane (c, g) = 8 columns x 8 rows: two global_load_dwordx3 per row,
+//          Rec.601 luma (exact integers), packed to f16; the 7 luma rows above come from the lane with g-1
+//          through LDS (or from the rows saved by the previous half tile / band), and the vertical 8-row
+//          window sums V (<= 2040, exact in f16) go to a 64x128 f16 tile in LDS.
 //   SCAN   lane r = image row: walks the tile left to right keeping the horizontal 8-window sum Hs
 //          of V in f32 (= the pass-1 box value x 64, an exact integer) and the reference's pass-2 row
 //          running sum (sum += in[ri]; sum -= in[li]) in the reference's order; emits the pass-2 row
@@ -31,14 +32,34 @@ namespace {
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-constexpr int TILE_PITCH = 144;                 // bytes per V-tile row: 64 f16 + 16 B pad (conflict-free b128 reads, lane = row)
-constexpr int OFF_TILE = 0;                     // 64 * 144 = 9216 B; the exchange area and the tail scratch alias it
-constexpr int OFF_STATE = 9216;                 // 7 luma rows x 512 columns, f16 = 7168 B
-constexpr int SAMP_PITCH = 33;                  // sample transpose buffer: 64 rows x 33 floats = 8448 B, aliases the dead V tile
-constexpr int OFF_EDGE = OFF_STATE + 7168;      // 6 chains x 64 rows x f32 = 1536 B (rv in, edge values out, in place)
-constexpr int LDS_BYTES = OFF_EDGE + 1536;      // 17920 B -> 9 waves per CU
-static_assert(64 * SAMP_PITCH * 4 <= 9216, "sample transpose buffer must fit in the dead V tile");
-static_assert(rph::TAIL_LDS_FLOATS * 4 <= 9216, "tail scratch must fit in the dead V tile");
+// Strip geometry.  Two builds of the same kernel:
+//   SW = 64 : 8 strips, tile 64x64, one build step per tile, 17.9 KB LDS -> 8 waves per CU (fastest: the kernel is
+//             VALU-issue bound, so the extra occupancy wins), but a strip row is 192 B = 1.5 cache lines, so every third
+//             line is requested by two tiles (L2->fabric traffic 1.30 x algorithmic, profiles/r01_pmc_summary.txt)
+//   SW = 128: 4 strips, tile 64x128 built as two 32-row halves, 26.1 KB LDS -> 6 waves per CU; a strip row is 384 B =
+//             exactly 3 lines, traffic 1.11 x algorithmic (the rest is the edge pre-pass)
+template <int SW_>
+struct Geo {
+    static constexpr int SW = SW_;                       // strip width in pixels
+    static constexpr int NSTRIP = 512 / SW;
+    static constexpr int CL = SW / 8;                    // lanes across a strip row, 8 px each
+    static constexpr int NG = 64 / CL;                   // lane groups of 8 rows -> NG * 8 rows per build step
+    static constexpr int NH = 64 / (NG * 8);             // build steps ("halves") per tile: 1 or 2
+    static constexpr int NOCT = SW / 8;                  // octets per strip in the scan
+    static constexpr int TILE_PITCH = SW * 2 + 16;       // bytes per V-tile row: SW f16 + 16 B pad (conflict-free b128 reads, lane = row)
+    static constexpr int TILE_BYTES = 64 * TILE_PITCH;   // the sample transpose buffer and the tail scratch alias the dead tile
+    static constexpr int OFF_TILE = 0;
+    // exchange area: NH == 2 -> rows 32..63 of the tile (dead, or not yet written, whenever it is used); NH == 1 -> the whole dead tile
+    static constexpr int OFF_XCHG = NH == 2 ? 32 * TILE_PITCH : 0;
+    static constexpr int OFF_STATE = TILE_BYTES;         // 7 luma rows x 512 columns, f16 = 7168 B
+    static constexpr int OFF_EDGE = OFF_STATE + 7168;    // 6 chains x 64 rows x f32 = 1536 B (rv in, edge values out, in place)
+    static constexpr int LDS_BYTES = OFF_EDGE + 1536;    // SW 64: 17920 B, SW 128: 26112 B
+    static constexpr int WAVES_PER_SIMD = 2;
+    static_assert(64 * 33 * 4 <= TILE_BYTES, "sample transpose buffer must fit in the dead V tile");
+    static_assert((NG - 1) * 7 * CL * 16 <= (NH == 2 ? 32 : 64) * TILE_PITCH, "exchange area must fit");
+    static_assert(rph::TAIL_LDS_FLOATS * 4 <= TILE_BYTES, "tail scratch must fit in the dead V tile");
+};
+constexpr int SAMP_PITCH = 33;                  // sample transpose buffer: 64 rows x 33 floats = 8448 B
 
 struct Px8 {  // 8 RGB pixels = 24 bytes = 6 dwords, loaded as 2 x dwordx3
     uint32_t d[6];
@@ -177,62 +198,64 @@ struct Wave {
     bool want_quality;
 };
 
-__device__ __forceinline__ const uint8_t *tile_px(const Wave &w, int b, int s, int k, int c, int g, bool &beyond)
-{
-    int y = 64 * b + 4 + 8 * g + k;
-    beyond = y >= 512;
-    y = beyond ? 511 : y;
-    return w.img + (size_t)y * w.row_stride + (size_t)(64 * s + 8 * c) * 3;
-}
+// luma row of lane group g, local row k, in half h of band b
+template <class G>
+__device__ __forceinline__ int half_row(int b, int h, int g, int k) { return 64 * b + 4 + (G::NG * 8) * h + 8 * g + k; }
 
-// LOAD phase 1: issue the 16 loads of tile (b, s)
-__device__ __forceinline__ void tile_issue(const Wave &w, int b, int s, Px8 (&pre)[8])
+// LOAD phase 1: issue the 16 loads of half tile (b, s, h)
+template <class G>
+__device__ __forceinline__ void half_issue(const Wave &w, int b, int s, int h, Px8 (&pre)[8])
 {
-    const int c = w.lane & 7, g = w.lane >> 3;
+    const int c = w.lane & (G::CL - 1), g = w.lane / G::CL;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        bool beyond;
-        pre[k] = load_px8(tile_px(w, b, s, k, c, g, beyond));
+        int y = half_row<G>(b, h, g, k);
+        y = y > 511 ? 511 : y;  // rows beyond the image are zeroed in half_luma
+        pre[k] = load_px8(w.img + (size_t)y * w.row_stride + (size_t)(G::SW * s + 8 * c) * 3);
     }
 }
 
-// LOAD phase 2a: luma of the 8 prefetched rows (frees the prefetch registers for the next tile's loads)
-template <bool LAST_BAND>
-__device__ __forceinline__ void tile_luma(const Wave &w, int b, const Px8 (&pre)[8], Row8 (&L)[8])
+// LOAD phase 2a: luma of the 8 prefetched rows (frees the prefetch registers for the next half tile's loads)
+template <class G, bool LAST_BAND>
+__device__ __forceinline__ void half_luma(const Wave &w, int b, int h, const Px8 (&pre)[8], Row8 (&L)[8])
 {
-    const int g = w.lane >> 3;
+    const int g = w.lane / G::CL;
 #pragma unroll
-    for (int k = 0; k < 8; k++) L[k] = pack_row(pre[k], LAST_BAND && (64 * b + 4 + 8 * g + k >= 512));
+    for (int k = 0; k < 8; k++) L[k] = pack_row(pre[k], LAST_BAND && (half_row<G>(b, h, g, k) >= 512));
 }
 
-// LOAD phase 2b: exchange of the 7 rows above, vertical window sums, V tile
-__device__ __forceinline__ void tile_build(Wave &w, int s, const Row8 (&L)[8])
+// LOAD phase 2b: exchange of the 7 rows above, vertical window sums, 32 rows of the V tile
+template <class G>
+__device__ __forceinline__ void half_build(Wave &w, int s, int h, const Row8 (&L)[8])
 {
-    const int c = w.lane & 7, g = w.lane >> 3;
-    uint8_t *tile = w.lds + OFF_TILE;
-    uint8_t *state = w.lds + OFF_STATE + (64 * s + 8 * c) * 2;
+    const int c = w.lane & (G::CL - 1), g = w.lane / G::CL;
+    uint8_t *tile = w.lds + G::OFF_TILE;
+    uint8_t *xchg = w.lds + G::OFF_XCHG;
+    uint8_t *state = w.lds + G::OFF_STATE + (G::SW * s + 8 * c) * 2;
 
-    // publish rows 1..7 for the lane below (g + 1); the tile is dead here (its scan is over)
-    if (g < 7) {
-        uint8_t *x = tile + ((g * 7) * 8 + c) * 16;
+    // publish rows 1..7 for the lane group below (g + 1)
+    if (g < G::NG - 1) {
+        uint8_t *x = xchg + ((g * 7) * G::CL + c) * 16;
 #pragma unroll
-        for (int k = 1; k < 8; k++) *reinterpret_cast<uint4 *>(x + (k - 1) * 128) = row_bits(L[k]);
+        for (int k = 1; k < 8; k++) *reinterpret_cast<uint4 *>(x + (k - 1) * (G::CL * 16)) = row_bits(L[k]);
     }
     wave_lds_fence();
-    // the 7 luma rows above this lane's first row: from lane g-1, or for g == 0 from the previous band
+    // the 7 luma rows above this lane's first row: from lane group g-1, or for g == 0 the rows saved by the
+    // previous half tile of these columns (previous band's second half, or this tile's first half)
     Row8 hist[7];
     {
-        const uint8_t *hp = (g == 0) ? state : tile + (((g - 1) * 7) * 8 + c) * 16;
-        const int stride = (g == 0) ? 1024 : 128;
+        const uint8_t *hp = (g == 0) ? state : xchg + (((g - 1) * 7) * G::CL + c) * 16;
+        const int stride = (g == 0) ? 1024 : G::CL * 16;
 #pragma unroll
         for (int j = 0; j < 7; j++) hist[j] = bits_row(*reinterpret_cast<const uint4 *>(hp + j * stride));
     }
     wave_lds_fence();
-    if (g == 7) {  // rows 1..7 of the last lane group are the next band's history for these columns
+    if (g == G::NG - 1) {  // rows 1..7 of the last lane group are the history of the next half tile of these columns
 #pragma unroll
         for (int k = 1; k < 8; k++) *reinterpret_cast<uint4 *>(state + (k - 1) * 1024) = row_bits(L[k]);
     }
-    // V[m] = sum of the 8 luma rows ending at own row m  (V row 64b + 8g + m = luma rows -3..+4 around it)
+    // V[m] = sum of the 8 luma rows ending at own row m  (V row = luma rows -3..+4 around it)
+    const int row0 = (G::NG * 8) * h + 8 * g;
     Row8 v;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -242,12 +265,12 @@ __device__ __forceinline__ void tile_build(Wave &w, int s, const Row8 (&L)[8])
         h2 dd = hist[6].q[i] + L[0].q[i];
         v.q[i] = (a + bb) + (cc + dd);
     }
-    *reinterpret_cast<uint4 *>(tile + (8 * g + 0) * TILE_PITCH + 16 * c) = row_bits(v);
+    *reinterpret_cast<uint4 *>(tile + (row0 + 0) * G::TILE_PITCH + 16 * c) = row_bits(v);
 #pragma unroll
     for (int m = 1; m < 8; m++) {
 #pragma unroll
         for (int i = 0; i < 4; i++) v.q[i] = (v.q[i] - hist[m - 1].q[i]) + L[m].q[i];  // subtract first: stays <= 2040
-        *reinterpret_cast<uint4 *>(tile + (8 * g + m) * TILE_PITCH + 16 * c) = row_bits(v);
+        *reinterpret_cast<uint4 *>(tile + (row0 + m) * G::TILE_PITCH + 16 * c) = row_bits(v);
     }
     wave_lds_fence();
 }
@@ -294,15 +317,15 @@ __device__ __forceinline__ float pass1_value(const Wave &w, float hs)
 }
 
 // SCAN of strip s of the current band.  FIRST/LAST: strip 0 / strip 7 (frame columns).
-template <bool EDGE_ROWS, bool FIRST, bool LAST>
+template <class G, bool EDGE_ROWS, bool FIRST, bool LAST>
 __device__ __forceinline__ void scan_strip(Wave &w)
 {
     const int r = w.lane;
-    const uint8_t *tp = w.lds + OFF_TILE + r * TILE_PITCH;
-    const float *edge = reinterpret_cast<const float *>(w.lds + OFF_EDGE);
-    float fresh[8];
+    const uint8_t *tp = w.lds + G::OFF_TILE + r * G::TILE_PITCH;
+    const float *edge = reinterpret_cast<const float *>(w.lds + G::OFF_EDGE);
+    float fresh[G::NOCT];
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < G::NOCT; q++) {
         const uint4 cur = *reinterpret_cast<const uint4 *>(tp + 16 * q);
         const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
         const uint32_t pw[4] = {w.pv.x, w.pv.y, w.pv.z, w.pv.w};
@@ -325,7 +348,7 @@ __device__ __forceinline__ void scan_strip(Wave &w)
     }
         RPH_STEP(0) RPH_STEP(1) RPH_STEP(2) RPH_STEP(3) RPH_STEP(4)
         // output o = xv - 8 = 8j + 4 right after element 4 of octet j + 1
-        fresh[q] = w.sum * 0.125f;  // sample slot 8 s + q (slot 0 of the image = octet 0 is a dummy)
+        fresh[q] = w.sum * 0.125f;  // sample slot G::NOCT * s + q (slot 0 of the image = octet 0 is a dummy)
         RPH_STEP(5) RPH_STEP(6) RPH_STEP(7)
 #undef RPH_STEP
         w.pv = cur;
@@ -346,9 +369,9 @@ __device__ __forceinline__ void scan_strip(Wave &w)
         w.smp_last = w.sum / 7.0f;
     }
 #pragma unroll
-    for (int i = 0; i < 24; i++) w.smp[i] = w.smp[i + 8];
+    for (int i = 0; i < 32 - G::NOCT; i++) w.smp[i] = w.smp[i + G::NOCT];
 #pragma unroll
-    for (int q = 0; q < 8; q++) w.smp[24 + q] = fresh[q];
+    for (int q = 0; q < G::NOCT; q++) w.smp[32 - G::NOCT + q] = fresh[q];
 }
 
 __device__ __forceinline__ void scan_reset(Wave &w, int b)
@@ -369,10 +392,11 @@ __device__ __forceinline__ void scan_reset(Wave &w, int b)
 // pass-2 column chain over the 64 rows of band b for the sampled columns of one half band.
 // First half: sample slots 0..31 = [dummy, j = 0..30] -> lanes j = 0..30 read slot j + 1.
 // Second half: slots 0..31 = j = 31..62, slot 32 = j = 63      -> lanes j = 31..63 read slot j - 31.
+template <class G>
 __device__ __forceinline__ void col_pass(Wave &w, int b, bool second_half)
 {
     // transpose through the V tile, which is dead between the last scan of the half band and the next tile build
-    float *tb = reinterpret_cast<float *>(w.lds + OFF_TILE);
+    float *tb = reinterpret_cast<float *>(w.lds + G::OFF_TILE);
 #pragma unroll
     for (int t = 0; t < 32; t++) tb[w.lane * SAMP_PITCH + t] = w.smp[t];
     tb[w.lane * SAMP_PITCH + 32] = w.smp_last;
@@ -427,9 +451,10 @@ __device__ __forceinline__ void edge_rowvals(const Wave &w, int y, bool live, fl
     }
 }
 
+template <class G>
 __device__ __forceinline__ void edge_prologue(Wave &w)
 {
-    float *edge = reinterpret_cast<float *>(w.lds + OFF_EDGE);
+    float *edge = reinterpret_cast<float *>(w.lds + G::OFF_EDGE);
     float rv[6];
     edge_rowvals(w, w.lane & 3, true, rv);
     if (w.lane < 4) {
@@ -451,10 +476,10 @@ __device__ __forceinline__ void edge_prologue(Wave &w)
     wave_lds_fence();
 }
 
-template <int KIND>  // 0 = first band, 1 = middle, 2 = last band
+template <class G, int KIND>  // 0 = first band, 1 = middle, 2 = last band
 __device__ __forceinline__ void edge_band(Wave &w, int b)
 {
-    float *edge = reinterpret_cast<float *>(w.lds + OFF_EDGE);
+    float *edge = reinterpret_cast<float *>(w.lds + G::OFF_EDGE);
     {
         float rv[6];
         const int y = 64 * b + 4 + w.lane;
@@ -496,30 +521,36 @@ __device__ __forceinline__ void edge_band(Wave &w, int b)
     wave_lds_fence();
 }
 
-template <int KIND>
+template <class G, int KIND>
 __device__ __forceinline__ void do_band(Wave &w, int b, Px8 (&pre)[8])
 {
     constexpr bool EDGE_ROWS = KIND != 1;
-    edge_band<KIND>(w, b);
+    edge_band<G, KIND>(w, b);
     scan_reset(w, b);
 #pragma unroll 1
-    for (int s = 0; s < 8; s++) {
-        Row8 L[8];
-        tile_luma<KIND == 2>(w, b, pre, L);
-        if (s < 7)
-            tile_issue(w, b, s + 1, pre);
-        else if (b < 7)
-            tile_issue(w, b + 1, 0, pre);
-        tile_build(w, s, L);
+    for (int s = 0; s < G::NSTRIP; s++) {
+#pragma unroll 1
+        for (int h = 0; h < G::NH; h++) {
+            Row8 L[8];
+            half_luma<G, KIND == 2>(w, b, h, pre, L);
+            // next build step in processing order: (b,s,1) -> (b,s+1,0) -> ... -> (b+1,0,0)
+            if (h + 1 < G::NH)
+                half_issue<G>(w, b, s, h + 1, pre);
+            else if (s < G::NSTRIP - 1)
+                half_issue<G>(w, b, s + 1, 0, pre);
+            else if (b < 7)
+                half_issue<G>(w, b + 1, 0, 0, pre);
+            half_build<G>(w, s, h, L);
+        }
         if (s == 0)
-            scan_strip<EDGE_ROWS, true, false>(w);
-        else if (s == 7)
-            scan_strip<EDGE_ROWS, false, true>(w);
+            scan_strip<G, EDGE_ROWS, true, false>(w);
+        else if (s == G::NSTRIP - 1)
+            scan_strip<G, EDGE_ROWS, false, true>(w);
         else
-            scan_strip<EDGE_ROWS, false, false>(w);
+            scan_strip<G, EDGE_ROWS, false, false>(w);
         wave_lds_fence();
-        if (s == 3) col_pass(w, b, false);
-        if (s == 7) col_pass(w, b, true);
+        if (s == G::NSTRIP / 2 - 1) col_pass<G>(w, b, false);
+        if (s == G::NSTRIP - 1) col_pass<G>(w, b, true);
         wave_lds_fence();
     }
     // band b completed decimated rows i = 8 b + u - 1 (u = 0 of band 0 is a dummy): feed them to the tail in order
@@ -528,11 +559,12 @@ __device__ __forceinline__ void do_band(Wave &w, int b, Px8 (&pre)[8])
         if (KIND != 0 || u > 0) rph::tail_row(w.tail, w.bnew[u], 8 * b + u - 1, w.lane, w.want_quality);
 }
 
-__global__ void __launch_bounds__(64, 2) pdq_fused512_kernel(const uint8_t *__restrict__ px, uint32_t n, size_t row_stride,
+template <class G>
+__global__ void __launch_bounds__(64, G::WAVES_PER_SIMD) pdq_fused512_kernel(const uint8_t *__restrict__ px, uint32_t n, size_t row_stride,
                                                           size_t image_stride, uint8_t *hash, float *quality, float *coeffs,
                                                           uint8_t *dihedral, uint8_t *valid)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[G::LDS_BYTES];
     const uint32_t img = blockIdx.x;
     Wave w;
     w.lds = lds;
@@ -552,24 +584,25 @@ __global__ void __launch_bounds__(64, 2) pdq_fused512_kernel(const uint8_t *__re
 
     // ---- prologue: luma rows 0..3 become the first band's history (rows -3..-1 are outside: zero)
     {
-        const int c = w.lane & 7, g = w.lane >> 3;
         for (int j = 0; j < 3; j++)
-            for (int t = w.lane; t < 64; t += 64) *reinterpret_cast<uint4 *>(lds + OFF_STATE + j * 1024 + t * 16) = make_uint4(0, 0, 0, 0);
+            for (int t = w.lane; t < 64; t += 64) *reinterpret_cast<uint4 *>(lds + G::OFF_STATE + j * 1024 + t * 16) = make_uint4(0, 0, 0, 0);
+        // rows 0..3 x 64 column chunks of 8 px = 256 (row, chunk) slots, 64 per iteration
 #pragma unroll 1
         for (int it = 0; it < 4; it++) {
-            const int s = 2 * it + (g >> 2), row = g & 3;
-            const Px8 p = load_px8(w.img + (size_t)row * row_stride + (size_t)(64 * s + 8 * c) * 3);
-            *reinterpret_cast<uint4 *>(lds + OFF_STATE + (3 + row) * 1024 + (64 * s + 8 * c) * 2) = row_bits(pack_row(p, false));
+            const int slot = it * 64 + w.lane;
+            const int chunk = slot & 63, row = slot >> 6;
+            const Px8 p = load_px8(w.img + (size_t)row * row_stride + (size_t)(8 * chunk) * 3);
+            *reinterpret_cast<uint4 *>(lds + G::OFF_STATE + (3 + row) * 1024 + (8 * chunk) * 2) = row_bits(pack_row(p, false));
         }
     }
-    edge_prologue(w);
+    edge_prologue<G>(w);
 
     Px8 pre[8];
-    tile_issue(w, 0, 0, pre);
-    do_band<0>(w, 0, pre);
+    half_issue<G>(w, 0, 0, 0, pre);
+    do_band<G, 0>(w, 0, pre);
 #pragma unroll 1
-    for (int b = 1; b < 7; b++) do_band<1>(w, b, pre);
-    do_band<2>(w, 7, pre);
+    for (int b = 1; b < 7; b++) do_band<G, 1>(w, b, pre);
+    do_band<G, 2>(w, 7, pre);
 
     // pass-2 column chain, phase 4 first step: out[508] = (csum - in[504]) / 7  (ring slot 0), unscale by 64
     w.csum = w.csum - w.cring[0];
@@ -587,10 +620,13 @@ int rph_launch_pdq_fused512(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, size_
                             uint8_t *d_hash, float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid,
                             hipStream_t stream)
 {
-    (void)ctx;
     if (n == 0) return RPH_OK;
-    hipLaunchKernelGGL(pdq_fused512_kernel, dim3(n), dim3(64), 0, stream, d_px, n, row_stride, image_stride, d_hash, d_quality,
-                       d_coeffs, d_dihedral, d_valid);
+    if (ctx->pdq_kernel == 2)
+        hipLaunchKernelGGL(pdq_fused512_kernel<Geo<128>>, dim3(n), dim3(64), 0, stream, d_px, n, row_stride, image_stride, d_hash,
+                           d_quality, d_coeffs, d_dihedral, d_valid);
+    else
+        hipLaunchKernelGGL(pdq_fused512_kernel<Geo<64>>, dim3(n), dim3(64), 0, stream, d_px, n, row_stride, image_stride, d_hash,
+                           d_quality, d_coeffs, d_dihedral, d_valid);
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }

@@ -199,7 +199,7 @@ void *rph_stream(rph_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int rph_pdq_set_kernel(rph_ctx *ctx, int which)
 {
-    if (!ctx || which < 0 || which > 1) return RPH_ERR_INVALID_ARG;
+    if (!ctx || which < 0 || which > 2) return RPH_ERR_INVALID_ARG;
     ctx->pdq_kernel = which;
     return RPH_OK;
 }
@@ -236,7 +236,7 @@ int rph_pdq_hash_batch_dev(rph_ctx *ctx, const void *d_px, uint32_t n, uint32_t 
                       w, h);
         return RPH_ERR_UNSUPPORTED;
     }
-    if (ctx->pdq_kernel == 1 && w == 512 && h == 512 && channels == 3 && (row_stride % 4) == 0 && (image_stride % 4) == 0 &&
+    if (ctx->pdq_kernel >= 1 && w == 512 && h == 512 && channels == 3 && (row_stride % 4) == 0 && (image_stride % 4) == 0 &&
         ((uintptr_t)d_px % 4) == 0) {
         int rc = rph_launch_pdq_fused512(ctx, (const uint8_t *)d_px, n, row_stride, image_stride, (uint8_t *)d_hash32,
                                          (float *)d_quality, (float *)d_coeffs, (uint8_t *)d_dihedral, (uint8_t *)d_valid, s);

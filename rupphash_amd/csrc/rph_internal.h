@@ -14,7 +14,7 @@ struct rph_ctx {
     // scratch for the generic (multi-pass) PDQ kernel: two f32 planes per in-flight image
     float *scratch = nullptr;
     size_t scratch_bytes = 0;
-    int pdq_kernel = 1;  // 1 = fused 512x512x3 kernel where it applies, 0 = always generic
+    int pdq_kernel = 1;  // 0 = always generic; 1 / 2 = fused 512x512x3 kernel (64- / 128-px strips) where it applies
 };
 
 void rph_set_error(const char *fmt, ...);

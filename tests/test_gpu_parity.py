@@ -353,10 +353,12 @@ def _fused_images():
     return np.stack(imgs)
 
 
-def test_fused512_kernel_matches_oracle_bit_for_bit(eng, oracle):
+@pytest.mark.parametrize("which", [1, 2])
+def test_fused512_kernel_matches_oracle_bit_for_bit(eng, oracle, which):
     imgs = _fused_images()
-    eng.set_pdq_kernel(1)
+    eng.set_pdq_kernel(which)
     out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
+    eng.set_pdq_kernel(1)
     for k in range(len(imgs)):
         rc, coeffs, q = oracle.pdq_features(imgs[k])
         assert rc == 0 and out["valid"][k] == 1
@@ -366,10 +368,13 @@ def test_fused512_kernel_matches_oracle_bit_for_bit(eng, oracle):
         assert np.array_equal(out["dihedral"][k], oracle.dihedral_hashes(coeffs)), k
 
 
-def test_fused512_on_synthetic_bench_images(eng, oracle):
+@pytest.mark.parametrize("which", [1, 2])
+def test_fused512_on_synthetic_bench_images(eng, oracle, which):
     """the bench workload itself: 24 images of the synthetic sequence (incl. a near-duplicate pair) vs the oracle"""
     imgs = eng.synth_images(990, 24)
+    eng.set_pdq_kernel(which)
     out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True)
+    eng.set_pdq_kernel(1)
     ref_hash, ref_q, ref_c = oracle.pdq_batch_rgb(imgs, want_coeffs=True)
     assert np.array_equal(out["hash"], ref_hash)
     assert np.array_equal(bits(out["coeffs"]), bits(ref_c)) and np.array_equal(bits(out["quality"]), bits(ref_q))
@@ -385,7 +390,7 @@ def test_fused512_equals_generic_on_4096_images(eng):
     res = []
     try:
         eng.synth_images_dev(d_img, 123_000, n)
-        for which in (1, 0):
+        for which in (1, 2, 0):
             eng.set_pdq_kernel(which)
             for p, nb in zip(bufs, (n * 32, n * 4, n * 1024)):
                 eng.dev_memset(p, 0xEE, nb)
@@ -398,8 +403,9 @@ def test_fused512_equals_generic_on_4096_images(eng):
         eng.set_pdq_kernel(1)
         for p in [d_img] + bufs:
             eng.dev_free(p)
-    assert np.array_equal(res[0][0], res[1][0])
-    assert np.array_equal(bits(res[0][1]), bits(res[1][1])) and np.array_equal(bits(res[0][2]), bits(res[1][2]))
+    for other in (1, 2):
+        assert np.array_equal(res[0][0], res[other][0])
+        assert np.array_equal(bits(res[0][1]), bits(res[other][1])) and np.array_equal(bits(res[0][2]), bits(res[other][2]))
     # every 1000-image stripe holds one known near-duplicate pair (k % 1000 == 999 shares blocks with k - 1)
     from rupphash_amd import hamminghash as hh
 
