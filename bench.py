@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--threshold", type=int, default=32)
     ap.add_argument("--hamming-steps", type=int, default=0, help="default: same as --steps")
     ap.add_argument("--pdq-kernel", type=int, default=1, help="1 = fused, 64-px strips (default), 2 = fused, 128-px strips, 0 = generic multi-pass")
+    ap.add_argument("--hamming-kernel", type=int, default=1, help="1 = int8 MFMA fast path (default), 0 = VALU xor + popcount")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline leg")
     args = ap.parse_args()
@@ -73,6 +74,7 @@ def main():
 
     eng = Engine(local_rank)
     eng.set_pdq_kernel(args.pdq_kernel)
+    eng.set_hamming_kernel(args.hamming_kernel)
     dev = torch.device("cuda", local_rank)
     # one explicit (non-null) HIP stream carries the kernels, torch's fills and the RCCL collective, so the
     # HIP events below bracket exactly the work they name

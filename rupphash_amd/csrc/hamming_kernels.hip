@@ -22,6 +22,15 @@
 //   - hits are appended to a global edge list through one atomic cursor.
 // The binding roof is integer VALU (2*PW lane-ops per pair), not HBM: the sweep
 // moves 64/T bytes per pair.
+//
+// Second formulation of the same fast path (default): hamming_mfma_kernel.  With bits encoded as
+// +-1 bytes, a 32-bit slice of the XOR-popcount is an int8 dot product: dot = 32 - 2 d.  One
+// v_mfma_i32_32x32x32_i8 therefore evaluates a 32-bit slice for 32 x 32 pairs in 32 cycles on the
+// matrix pipe (8 pairs/clk/SIMD per slice against 64 lanes / 6 clk for v_xor + v_bcnt, which is a
+// half-rate VALU op on gfx950 -- tools/valu_rate.hip), exactly (int32 accumulation), and the VALU
+// is left with one max-reduction per tile.  Row fragments stay in VGPRs, the column tile is
+// expanded to +-1 bytes once per chunk through a 256-entry LUT in LDS.  Candidates (partial
+// distance <= threshold) go through the same exact completion as the VALU kernel.
 #include "rph_internal.h"
 
 namespace {
@@ -77,6 +86,7 @@ __device__ __forceinline__ void complete_pair(const SweepArgs &a, const uint32_t
         d += (uint32_t)__builtin_popcount(x[w]);
     }
     if (variant > 0 && a.has_features && !a.has_features[owner]) return;
+    if (col >= a.n) return;
     if (col <= owner) return;  // i < j only (scanner.rs:1716 `cand_idx <= i`, hamminghash.rs:216 `dense_idx == i`)
     uint32_t limit = a.threshold;
     if (a.low_conf && (a.low_conf[owner] | a.low_conf[col])) limit = 0;  // scanner.rs:1699,1721
@@ -176,11 +186,132 @@ __global__ void __launch_bounds__(BLOCK) hamming_sweep_kernel(SweepArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// MFMA formulation of the fast path
+// ---------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int MF_BLOCK = 256;   // 4 waves; wave w owns rows 256 w .. 256 w + 255 of the 1024-row tile
+constexpr int MF_RB = 8;        // 32-row blocks per wave
+constexpr int MF_CHUNK = 128;   // columns expanded into LDS at a time
+
+// byte v -> 8 bytes, byte i = bit i of v ? +1 : -1
+__device__ __forceinline__ uint2 expand_byte(uint32_t v)
+{
+    uint2 r;
+    const uint32_t lo = ((v & 0xFu) * 0x00204081u) & 0x01010101u;
+    const uint32_t hi = (((v >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
+    r.x = 0xFFFFFFFFu ^ (lo * 0xFEu);  // 1 -> 0x01, 0 -> 0xFF, no carries between bytes
+    r.y = 0xFFFFFFFFu ^ (hi * 0xFEu);
+    return r;
+}
+
+template <int PW>
+__global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
+{
+    constexpr int PITCH = 2 * PW * 16 + 16;  // bytes per column: [k-half h][dword kb][16 x i8] + pad (conflict-free b128, lane = column)
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[MF_CHUNK * PITCH];
+    __shared__ uint2 s_lut[256];
+
+    const unsigned long long p = (unsigned long long)a.part + (unsigned long long)blockIdx.x * a.nparts;
+    if (p >= a.n_tile_pairs) return;
+    uint32_t I, J;
+    tile_pair(p, a.n_tiles, I, J);
+    const unsigned long long col0 = (unsigned long long)J * T_FILES;
+    const unsigned long long row0 = (unsigned long long)I * T_FILES;
+    const uint32_t ncols = (uint32_t)((a.n - col0) < (unsigned long long)T_FILES ? (a.n - col0) : T_FILES);
+
+    s_lut[threadIdx.x] = expand_byte(threadIdx.x);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c32 = lane & 31, h = lane >> 5;
+    const int thresh_dot = 32 * PW - 2 * (int)a.threshold;  // partial distance <= threshold  <=>  dot >= 32 PW - 2 threshold
+    const uint32_t nv = a.n_variants;
+
+    for (uint32_t v = 0; v < nv; v++) {
+        // A fragments: row block rb, dword kb: this lane (row c32, half h) holds the 16 bits [32 kb + 16 h, +16) of its row
+        v4i A[MF_RB][PW];
+#pragma unroll
+        for (int rb = 0; rb < MF_RB; rb++) {
+            const unsigned long long owner = row0 + 256ull * wave + 32ull * rb + c32;
+            const uint32_t *rp = a.rows + ((owner < a.n ? owner : 0ull) * nv + v) * 8;
+            uint32_t d[8];
+            const uint4 lo = *reinterpret_cast<const uint4 *>(rp);
+            d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w;
+            if (PW > 4) {
+                const uint4 hi = *reinterpret_cast<const uint4 *>(rp + 4);
+                d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
+            }
+#pragma unroll
+            for (int kb = 0; kb < PW; kb++) {
+                const uint32_t hw = (d[kb] >> (16 * h)) & 0xFFFFu;
+                const uint2 e0 = s_lut[hw & 0xFFu], e1 = s_lut[hw >> 8];
+                A[rb][kb] = v4i{(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
+            }
+        }
+
+        for (uint32_t cbase = 0; cbase < ncols; cbase += MF_CHUNK) {
+            __syncthreads();  // everyone is done with the previous chunk
+            // expand MF_CHUNK columns x PW dwords: one (column, dword) per thread iteration -> 4 x 8 expanded bytes
+            for (uint32_t t = threadIdx.x; t < MF_CHUNK * PW; t += MF_BLOCK) {
+                const uint32_t col = t / PW, kb = t % PW;
+                uint32_t dwd = 0;
+                const bool live = cbase + col < ncols;
+                if (live) dwd = a.cols[(col0 + cbase + col) * 8 + kb];
+                uint8_t *dst = s_b + col * PITCH + kb * 16;
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++) {
+                    const uint32_t hw = (dwd >> (16 * hh)) & 0xFFFFu;
+                    uint2 e0 = s_lut[hw & 0xFFu], e1 = s_lut[hw >> 8];
+                    if (!live) e0 = e1 = make_uint2(0, 0);  // zero bytes: dot 0, never a candidate unless every pair is
+                    *reinterpret_cast<uint4 *>(dst + hh * PW * 16) = make_uint4(e0.x, e0.y, e1.x, e1.y);
+                }
+            }
+            __syncthreads();
+
+#pragma unroll 1
+            for (int cb = 0; cb < MF_CHUNK / 32; cb++) {
+                if (cbase + cb * 32 >= ncols) break;
+                v4i B[PW];
+                const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * PW * 16;
+#pragma unroll
+                for (int kb = 0; kb < PW; kb++) B[kb] = *reinterpret_cast<const v4i *>(bp + kb * 16);
+#pragma unroll
+                for (int rb = 0; rb < MF_RB; rb++) {
+                    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int kb = 0; kb < PW; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[rb][kb], B[kb], acc, 0, 0, 0);
+                    int m = acc[0];
+#pragma unroll
+                    for (int r = 1; r < 16; r++) m = acc[r] > m ? acc[r] : m;
+                    if (m >= thresh_dot) {  // rare: complete the candidates of this 32 x 32 tile exactly
+                        uint32_t hit = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) hit |= (acc[r] >= thresh_dot ? 1u : 0u) << r;
+                        const unsigned long long col = col0 + cbase + cb * 32 + c32;  // C/D layout: column = lane & 31
+                        while (hit) {
+                            const int r = __builtin_ctz(hit);
+                            hit &= hit - 1;
+                            // C/D layout: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                            const unsigned long long owner = row0 + 256ull * wave + 32ull * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (owner < a.n)
+                                complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
                              const uint8_t *d_has_features, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts, rph_edge *d_edges,
-                             uint64_t cap, unsigned long long *d_count, hipStream_t stream)
+                             uint64_t cap, unsigned long long *d_count, hipStream_t stream, int use_mfma)
 {
     if (nparts == 0 || part >= nparts || (n_variants != 1 && n_variants != 8) || n > 0xFFFFFFFFull) {
         rph_set_error("hamming sweep: bad arguments (n=%llu variants=%u part=%u/%u)", (unsigned long long)n, n_variants,
@@ -213,6 +344,21 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
     // Partial-width test: unrelated 256-bit hashes differ in ~16*PW +- sqrt(8*PW) of the first
     // 32*PW bits; keep ~5 sigma between that and the threshold.
     const dim3 grid((unsigned)mine), block(BLOCK);
+    if (use_mfma) {
+        const dim3 mblock(MF_BLOCK);
+        if (a.threshold <= 36)
+            hipLaunchKernelGGL(hamming_mfma_kernel<4>, grid, mblock, 0, stream, a);
+        else if (a.threshold <= 48)
+            hipLaunchKernelGGL(hamming_mfma_kernel<5>, grid, mblock, 0, stream, a);
+        else if (a.threshold <= 60)
+            hipLaunchKernelGGL(hamming_mfma_kernel<6>, grid, mblock, 0, stream, a);
+        else if (a.threshold <= 74)
+            hipLaunchKernelGGL(hamming_mfma_kernel<7>, grid, mblock, 0, stream, a);
+        else
+            hipLaunchKernelGGL(hamming_mfma_kernel<8>, grid, mblock, 0, stream, a);
+        RPH_HIP_CHECK(hipGetLastError());
+        return RPH_OK;
+    }
     if (a.threshold <= 36)
         hipLaunchKernelGGL(hamming_sweep_kernel<4>, grid, block, 0, stream, a);
     else if (a.threshold <= 48)

@@ -82,7 +82,7 @@ static int sweep_host(rph_ctx *ctx, const uint8_t *variants, uint32_t n_variants
     RPH_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, 8, ctx->stream));
     RPH_TRY(rph_launch_hamming_sweep(rows, n_variants, (const uint8_t *)d_h.p, (const uint8_t *)d_lc.p,
                                      (const uint8_t *)d_hf.p, n, thr, part, nparts, (rph_edge *)d_e.p, cap,
-                                     (unsigned long long *)d_cnt.p, ctx->stream));
+                                     (unsigned long long *)d_cnt.p, ctx->stream, ctx->hamming_kernel));
     unsigned long long cnt = 0;
     RPH_HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -196,6 +196,13 @@ int rph_synchronize(rph_ctx *ctx)
 }
 
 void *rph_stream(rph_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int rph_hamming_set_kernel(rph_ctx *ctx, int which)
+{
+    if (!ctx || which < 0 || which > 1) return RPH_ERR_INVALID_ARG;
+    ctx->hamming_kernel = which;
+    return RPH_OK;
+}
 
 int rph_pdq_set_kernel(rph_ctx *ctx, int which)
 {
@@ -330,7 +337,8 @@ int rph_hamming_all_pairs_dev(rph_ctx *ctx, const void *d_hashes32, uint64_t n, 
     }
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
     return rph_launch_hamming_sweep((const uint8_t *)d_hashes32, 1, (const uint8_t *)d_hashes32, nullptr, nullptr, n, threshold,
-                                    part, nparts, (rph_edge *)d_edges, cap, (unsigned long long *)d_count, pick(ctx, stream));
+                                    part, nparts, (rph_edge *)d_edges, cap, (unsigned long long *)d_count, pick(ctx, stream),
+                                    ctx->hamming_kernel);
 }
 
 int rph_hamming_variant_pairs_dev(rph_ctx *ctx, const void *d_variants, uint32_t n_variants, const void *d_hashes32,
@@ -344,7 +352,7 @@ int rph_hamming_variant_pairs_dev(rph_ctx *ctx, const void *d_variants, uint32_t
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
     return rph_launch_hamming_sweep((const uint8_t *)d_variants, n_variants, (const uint8_t *)d_hashes32,
                                     (const uint8_t *)d_low_conf, nullptr, n, similarity, part, nparts, (rph_edge *)d_edges, cap,
-                                    (unsigned long long *)d_count, pick(ctx, stream));
+                                    (unsigned long long *)d_count, pick(ctx, stream), ctx->hamming_kernel);
 }
 
 int rph_hamming_all_pairs(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t threshold, uint32_t part,

@@ -14,6 +14,7 @@ struct rph_ctx {
     // scratch for the generic (multi-pass) PDQ kernel: two f32 planes per in-flight image
     float *scratch = nullptr;
     size_t scratch_bytes = 0;
+    int hamming_kernel = 1;  // 1 = int8 MFMA formulation of the sweep's fast path, 0 = VALU xor + popcount
     int pdq_kernel = 1;  // 0 = always generic; 1 / 2 = fused 512x512x3 kernel (64- / 128-px strips) where it applies
 };
 
@@ -40,7 +41,7 @@ int rph_launch_pdq_from_coeffs(const float *d_coeffs, uint32_t n, uint8_t *d_has
 // hamming_kernels.hip
 int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
                              const uint8_t *d_has_features, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts, rph_edge *d_edges,
-                             uint64_t cap, unsigned long long *d_count, hipStream_t stream);
+                             uint64_t cap, unsigned long long *d_count, hipStream_t stream, int use_mfma);
 int rph_launch_mih_build256(rph_ctx *ctx, const uint8_t *d_hashes, uint64_t n, uint32_t *d_offsets, uint32_t *d_values,
                             hipStream_t stream);
 // synth_kernels.hip

@@ -55,6 +55,9 @@ class Engine:
     def set_pdq_kernel(self, which):
         check(self.L.rph_pdq_set_kernel(self.ctx, which), "rph_pdq_set_kernel")
 
+    def set_hamming_kernel(self, which):
+        check(self.L.rph_hamming_set_kernel(self.ctx, which), "rph_hamming_set_kernel")
+
     # ---- PDQ ----
     def pdq_hash_batch(self, images, want_quality=True, want_coeffs=False, want_dihedral=False):
         """images: uint8 (n,h,w,3|4) or (n,h,w) [Luma8].  Returns dict(hash, quality, coeffs, dihedral, valid)."""

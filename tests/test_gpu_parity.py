@@ -166,13 +166,22 @@ def test_dihedral_hashes_match_physically_transformed_image(eng, oracle):
 
 
 # ------------------------------------------------------------------ Hamming sweep
-@pytest.mark.parametrize("thr", [0, 10, 31, 32, 36, 37, 48, 49, 60, 61, 74, 75, 100])
-def test_all_pairs_matches_brute_force(eng, oracle, thr):
+@pytest.mark.parametrize("kernel", [1, 0])  # 1 = int8 MFMA fast path (default), 0 = VALU xor + popcount
+@pytest.mark.parametrize("thr", [0, 10, 31, 32, 36, 37, 48, 49, 60, 61, 74, 75, 100, 200])
+def test_all_pairs_matches_brute_force(eng, oracle, thr, kernel):
     rng = np.random.default_rng(300 + thr)
     hashes = clustered_hashes(rng, 2500, 60, min(thr + 20, 120))
+    eng.set_hamming_kernel(kernel)
     got = eng.hamming_all_pairs(hashes, thr)
+    eng.set_hamming_kernel(1)
     want = oracle.all_pairs256(hashes, thr)
     assert edge_set(got) == sorted(map(tuple, want.tolist()))
+    if thr == 32:  # flags (find_groups reachability / probe slot) agree between the two formulations
+        eng.set_hamming_kernel(1 - kernel)
+        other = eng.hamming_all_pairs(hashes, thr)
+        eng.set_hamming_kernel(1)
+        key = lambda e: sorted((int(x["i"]), int(x["j"]), int(x["d"]), int(x["flags"])) for x in e)
+        assert key(got) == key(other)
 
 
 def test_all_pairs_sharded_over_parts(eng, oracle):
@@ -282,7 +291,8 @@ def test_mih_build_matches_reference_csr(eng, oracle):
 
 
 # ------------------------------------------------------------------ full-size, construction-known answers
-def test_one_million_hashes_threshold_32(eng, oracle):
+@pytest.mark.parametrize("kernel", [1, 0])
+def test_one_million_hashes_threshold_32(eng, oracle, kernel):
     """BASELINE config 3: 1M synthetic hashes, 1000 injected 5-member clusters + the distance-32 pair.
     The expected edge set follows from the construction (random 256-bit pairs at d <= 32 have
     probability ~1e-33), so the full-size sweep is checked exactly."""
@@ -294,8 +304,10 @@ def test_one_million_hashes_threshold_32(eng, oracle):
     try:
         eng.synth_hashes_dev(d_h, 0, n, n, n_clusters=nc)
         eng.dev_memset(d_c, 0, 8)
+        eng.set_hamming_kernel(kernel)
         eng.hamming_all_pairs_dev(d_h, n, 32, d_e, cap, d_c)
         eng.synchronize()
+        eng.set_hamming_kernel(1)
         cnt = np.zeros(1, np.uint64)
         eng.dev_download(cnt, d_c)
         from rupphash_amd import EDGE_DTYPE
