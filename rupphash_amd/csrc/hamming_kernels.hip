@@ -212,7 +212,7 @@ template <int PW>
 __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
 {
     constexpr int PITCH = 2 * PW * 16 + 16;  // bytes per column: [k-half h][dword kb][16 x i8] + pad (conflict-free b128, lane = column)
-    __shared__ __attribute__((aligned(16))) uint8_t s_b[MF_CHUNK * PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * MF_CHUNK * PITCH];
     __shared__ uint2 s_lut[256];
 
     const unsigned long long p = (unsigned long long)a.part + (unsigned long long)blockIdx.x * a.nparts;
@@ -253,24 +253,43 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
             }
         }
 
-        for (uint32_t cbase = 0; cbase < ncols; cbase += MF_CHUNK) {
-            __syncthreads();  // everyone is done with the previous chunk
-            // expand MF_CHUNK columns x PW dwords: one (column, dword) per thread iteration -> 4 x 8 expanded bytes
-            for (uint32_t t = threadIdx.x; t < MF_CHUNK * PW; t += MF_BLOCK) {
+        // column chunks are double buffered: the packed dwords of chunk i + 1 are fetched into registers before chunk i
+        // is swept and expanded into the other LDS buffer afterwards, so global latency never sits between two chunks
+        constexpr int PER_THREAD = (MF_CHUNK * PW + MF_BLOCK - 1) / MF_BLOCK;
+        uint32_t pre[PER_THREAD];
+        auto fetch = [&](uint32_t cbase) {
+#pragma unroll
+            for (int q = 0; q < PER_THREAD; q++) {
+                const uint32_t t = threadIdx.x + q * MF_BLOCK;
                 const uint32_t col = t / PW, kb = t % PW;
-                uint32_t dwd = 0;
+                pre[q] = (t < MF_CHUNK * PW && cbase + col < ncols) ? a.cols[(col0 + cbase + col) * 8 + kb] : 0u;
+            }
+        };
+        auto expand = [&](uint32_t cbase, uint8_t *buf) {
+#pragma unroll
+            for (int q = 0; q < PER_THREAD; q++) {
+                const uint32_t t = threadIdx.x + q * MF_BLOCK;
+                if (t >= MF_CHUNK * PW) continue;
+                const uint32_t col = t / PW, kb = t % PW;
                 const bool live = cbase + col < ncols;
-                if (live) dwd = a.cols[(col0 + cbase + col) * 8 + kb];
-                uint8_t *dst = s_b + col * PITCH + kb * 16;
+                uint8_t *dst = buf + col * PITCH + kb * 16;
 #pragma unroll
                 for (int hh = 0; hh < 2; hh++) {
-                    const uint32_t hw = (dwd >> (16 * hh)) & 0xFFFFu;
+                    const uint32_t hw = (pre[q] >> (16 * hh)) & 0xFFFFu;
                     uint2 e0 = s_lut[hw & 0xFFu], e1 = s_lut[hw >> 8];
                     if (!live) e0 = e1 = make_uint2(0, 0);  // zero bytes: dot 0, never a candidate unless every pair is
                     *reinterpret_cast<uint4 *>(dst + hh * PW * 16) = make_uint4(e0.x, e0.y, e1.x, e1.y);
                 }
             }
-            __syncthreads();
+        };
+        __syncthreads();  // previous variant's last chunk is finished
+        fetch(0);
+        int which = 0;
+        for (uint32_t cbase = 0; cbase < ncols; cbase += MF_CHUNK, which ^= 1) {
+            uint8_t *s_b = s_buf + which * (MF_CHUNK * PITCH);
+            expand(cbase, s_b);
+            __syncthreads();  // chunk visible; also orders this expand after the sweep of the chunk two steps back
+            if (cbase + MF_CHUNK < ncols) fetch(cbase + MF_CHUNK);
 
 #pragma unroll 1
             for (int cb = 0; cb < MF_CHUNK / 32; cb++) {
@@ -279,11 +298,10 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
                 const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * PW * 16;
 #pragma unroll
                 for (int kb = 0; kb < PW; kb++) B[kb] = *reinterpret_cast<const v4i *>(bp + kb * 16);
-#pragma unroll
-                for (int rb = 0; rb < MF_RB; rb++) {
-                    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int kb = 0; kb < PW; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[rb][kb], B[kb], acc, 0, 0, 0);
+                // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
+                // independent one every 32: tools/mfma_rate.hip), then both tiles are screened on the VALU while the
+                // other wave of the SIMD owns the matrix pipe
+                auto screen = [&](const v16i &acc, int rb) {
                     int m = acc[0];
 #pragma unroll
                     for (int r = 1; r < 16; r++) m = acc[r] > m ? acc[r] : m;
@@ -301,6 +319,18 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
                                 complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
                         }
                     }
+                };
+#pragma unroll
+                for (int rb = 0; rb < MF_RB; rb += 2) {
+                    v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    v16i acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int kb = 0; kb < PW; kb++) {
+                        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[rb][kb], B[kb], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[rb + 1][kb], B[kb], acc1, 0, 0, 0);
+                    }
+                    screen(acc0, rb);
+                    screen(acc1, rb + 1);
                 }
             }
         }
