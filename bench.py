@@ -24,7 +24,8 @@ sys.path.insert(0, ROOT)
 IMG_BYTES = 512 * 512 * 3
 ALGO_BYTES_PER_IMAGE = IMG_BYTES + 32          # 786 432 B read + 32 B hash written
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6e12
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6e12 (full-rate VOP2 ops only)
+MFMA_I8_OPS_PER_S = 256 * 4 * (32 * 32 * 32 * 2) / 32 * 2.4e9  # v_mfma_i32_32x32x32_i8: 65 536 ops / 32 clk / SIMD = 5.03e15
 
 
 def usable_cores():
@@ -172,7 +173,18 @@ def main():
         n_edges = int(t.item())
     expected_edges = n_clusters * 10 + (1 if n_h >= 10 else 0)
     pw = 4 if args.threshold <= 36 else 5 if args.threshold <= 48 else 6 if args.threshold <= 60 else 7 if args.threshold <= 74 else 8
-    lane_ops = 2 * pw * (n_pairs / world) / (h_kernel_ms * 1e-3)  # executed xor+bcnt lane-ops/s on this rank
+    pairs_per_s_rank = (n_pairs / world) / (h_kernel_ms * 1e-3)
+    if args.hamming_kernel == 1:
+        # int8 MFMA fast path: one v_mfma_i32_32x32x32_i8 (65 536 int8 ops) per 32-bit slice of 1024 pairs -> 64 * PW ops per pair
+        h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": MFMA_I8_OPS_PER_S / 1e12,
+                  "unit": "TOP/s (int8)", "frac": pairs_per_s_rank * 64 * pw / MFMA_I8_OPS_PER_S, "prefix_dwords": pw,
+                  "int8_ops_per_pair": 64 * pw, "hbm_bytes_per_pair": 64.0 / 1024, "kernel_ms": h_kernel_ms, "kernel": "hamming_mfma_kernel"}
+    else:
+        lane_ops = 2 * pw * pairs_per_s_rank  # executed xor + bcnt lane-ops/s on this rank
+        h_roof = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12, "unit": "Tlane-op/s",
+                  "frac": lane_ops / VALU_LANE_OPS_PER_S, "prefix_dwords": pw, "lane_ops_per_pair": 2 * pw,
+                  "hbm_bytes_per_pair": 64.0 / 1024, "kernel_ms": h_kernel_ms, "kernel": "hamming_sweep_kernel",
+                  "note": "v_bcnt_u32_b32 is a half-rate op on gfx950 (tools/valu_rate.hip): the xor+bcnt bound is 6 clk per dword per wave"}
 
     result = {
         "metric": "pdq_hashes_per_sec_512x512_rgb",
@@ -199,9 +211,7 @@ def main():
                     "scaling": "weak (pairs per GPU fixed: n = 1M*sqrt(N))", "edges_found": n_edges,
                     "edges_expected": expected_edges,
                     "exchange": "RCCL all-gather of hash shards" if world > 1 else "none (1 GPU)",
-                    "roofline": {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
-                                 "unit": "Tlane-op/s", "frac": lane_ops / VALU_LANE_OPS_PER_S, "prefix_dwords": pw,
-                                 "lane_ops_per_pair": 2 * pw, "hbm_bytes_per_pair": 64.0 / 1024, "kernel_ms": h_kernel_ms}},
+                    "roofline": h_roof},
     }
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)

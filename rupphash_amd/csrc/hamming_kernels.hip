@@ -194,8 +194,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int MF_BLOCK = 256;   // 4 waves; wave w owns rows 256 w .. 256 w + 255 of the 1024-row tile
-constexpr int MF_RB = 8;        // 32-row blocks per wave
-constexpr int MF_CHUNK = 128;   // columns expanded into LDS at a time
 
 // byte v -> 8 bytes, byte i = bit i of v ? +1 : -1
 __device__ __forceinline__ uint2 expand_byte(uint32_t v)
@@ -212,8 +210,14 @@ template <int PW>
 __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
 {
     constexpr int PITCH = 2 * PW * 16 + 16;  // bytes per column: [k-half h][dword kb][16 x i8] + pad (conflict-free b128, lane = column)
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * MF_CHUNK * PITCH];
+    constexpr int CHUNK = PW <= 4 ? 256 : 128;  // columns expanded into LDS at a time (two buffers)
+    constexpr int QCAP = 256;                // candidate queue per wave and chunk; overflow falls back to an exhaustive completion
+    constexpr int MF_RB = PW <= 4 ? 8 : 4;   // 32-row blocks per wave and pass (A fragments: MF_RB * PW * 4 VGPRs)
+    constexpr int PASS_ROWS = 4 * 32 * MF_RB; // rows one pass of the 4 waves covers; T_FILES / PASS_ROWS passes per tile
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * CHUNK * PITCH];
     __shared__ uint2 s_lut[256];
+    __shared__ uint32_t s_q[4][QCAP];   // one queue per wave: filled and drained by the same wave, no barrier needed
+    __shared__ uint32_t s_qn[4];
 
     const unsigned long long p = (unsigned long long)a.part + (unsigned long long)blockIdx.x * a.nparts;
     if (p >= a.n_tile_pairs) return;
@@ -224,6 +228,7 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
     const uint32_t ncols = (uint32_t)((a.n - col0) < (unsigned long long)T_FILES ? (a.n - col0) : T_FILES);
 
     s_lut[threadIdx.x] = expand_byte(threadIdx.x);
+    if (threadIdx.x < 4) s_qn[threadIdx.x] = 0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -231,12 +236,14 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
     const int thresh_dot = 32 * PW - 2 * (int)a.threshold;  // partial distance <= threshold  <=>  dot >= 32 PW - 2 threshold
     const uint32_t nv = a.n_variants;
 
-    for (uint32_t v = 0; v < nv; v++) {
+    for (uint32_t vp = 0; vp < nv * (T_FILES / PASS_ROWS); vp++) {
+        const uint32_t v = vp / (T_FILES / PASS_ROWS);
+        const uint32_t wrow = (vp % (T_FILES / PASS_ROWS)) * PASS_ROWS + wave * 32 * MF_RB;  // first tile row of this wave in this pass
         // A fragments: row block rb, dword kb: this lane (row c32, half h) holds the 16 bits [32 kb + 16 h, +16) of its row
         v4i A[MF_RB][PW];
 #pragma unroll
         for (int rb = 0; rb < MF_RB; rb++) {
-            const unsigned long long owner = row0 + 256ull * wave + 32ull * rb + c32;
+            const unsigned long long owner = row0 + wrow + 32ull * rb + c32;
             const uint32_t *rp = a.rows + ((owner < a.n ? owner : 0ull) * nv + v) * 8;
             uint32_t d[8];
             const uint4 lo = *reinterpret_cast<const uint4 *>(rp);
@@ -253,23 +260,23 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
             }
         }
 
-        // column chunks are double buffered: the packed dwords of chunk i + 1 are fetched into registers before chunk i
+        // column chunks are double buffered: the packed dwords of chunk i + 1 are fetched into registers while chunk i
         // is swept and expanded into the other LDS buffer afterwards, so global latency never sits between two chunks
-        constexpr int PER_THREAD = (MF_CHUNK * PW + MF_BLOCK - 1) / MF_BLOCK;
+        constexpr int PER_THREAD = (CHUNK * PW + MF_BLOCK - 1) / MF_BLOCK;
         uint32_t pre[PER_THREAD];
         auto fetch = [&](uint32_t cbase) {
 #pragma unroll
             for (int q = 0; q < PER_THREAD; q++) {
                 const uint32_t t = threadIdx.x + q * MF_BLOCK;
                 const uint32_t col = t / PW, kb = t % PW;
-                pre[q] = (t < MF_CHUNK * PW && cbase + col < ncols) ? a.cols[(col0 + cbase + col) * 8 + kb] : 0u;
+                pre[q] = (t < CHUNK * PW && cbase + col < ncols) ? a.cols[(col0 + cbase + col) * 8 + kb] : 0u;
             }
         };
         auto expand = [&](uint32_t cbase, uint8_t *buf) {
 #pragma unroll
             for (int q = 0; q < PER_THREAD; q++) {
                 const uint32_t t = threadIdx.x + q * MF_BLOCK;
-                if (t >= MF_CHUNK * PW) continue;
+                if (t >= CHUNK * PW) continue;
                 const uint32_t col = t / PW, kb = t % PW;
                 const bool live = cbase + col < ncols;
                 uint8_t *dst = buf + col * PITCH + kb * 16;
@@ -282,44 +289,42 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
                 }
             }
         };
-        __syncthreads();  // previous variant's last chunk is finished
         fetch(0);
         int which = 0;
-        for (uint32_t cbase = 0; cbase < ncols; cbase += MF_CHUNK, which ^= 1) {
-            uint8_t *s_b = s_buf + which * (MF_CHUNK * PITCH);
+        for (uint32_t cbase = 0; cbase < ncols; cbase += CHUNK, which ^= 1) {
+            uint8_t *s_b = s_buf + which * (CHUNK * PITCH);
             expand(cbase, s_b);
-            __syncthreads();  // chunk visible; also orders this expand after the sweep of the chunk two steps back
-            if (cbase + MF_CHUNK < ncols) fetch(cbase + MF_CHUNK);
+            __syncthreads();  // chunk visible (and the queue reset of the previous chunk)
+            if (cbase + CHUNK < ncols) fetch(cbase + CHUNK);
 
+            // ---- fast path: MFMA + VALU screen only.  No global memory operation lives in this loop (candidates go to
+            // an LDS queue), so the compiler never has to drain vmcnt here and the prefetch above stays in flight.
 #pragma unroll 1
-            for (int cb = 0; cb < MF_CHUNK / 32; cb++) {
+            for (int cb = 0; cb < CHUNK / 32; cb++) {
                 if (cbase + cb * 32 >= ncols) break;
                 v4i B[PW];
                 const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * PW * 16;
 #pragma unroll
                 for (int kb = 0; kb < PW; kb++) B[kb] = *reinterpret_cast<const v4i *>(bp + kb * 16);
-                // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
-                // independent one every 32: tools/mfma_rate.hip), then both tiles are screened on the VALU while the
-                // other wave of the SIMD owns the matrix pipe
                 auto screen = [&](const v16i &acc, int rb) {
                     int m = acc[0];
 #pragma unroll
                     for (int r = 1; r < 16; r++) m = acc[r] > m ? acc[r] : m;
-                    if (m >= thresh_dot) {  // rare: complete the candidates of this 32 x 32 tile exactly
-                        uint32_t hit = 0;
+                    if (m >= thresh_dot) {  // rare
 #pragma unroll
-                        for (int r = 0; r < 16; r++) hit |= (acc[r] >= thresh_dot ? 1u : 0u) << r;
-                        const unsigned long long col = col0 + cbase + cb * 32 + c32;  // C/D layout: column = lane & 31
-                        while (hit) {
-                            const int r = __builtin_ctz(hit);
-                            hit &= hit - 1;
-                            // C/D layout: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-                            const unsigned long long owner = row0 + 256ull * wave + 32ull * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            if (owner < a.n)
-                                complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                        for (int r = 0; r < 16; r++) {
+                            if (acc[r] >= thresh_dot) {
+                                // C/D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                                const uint32_t row_in_tile = wrow + 32u * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                const uint32_t col_in_chunk = cb * 32 + c32;
+                                const uint32_t at = atomicAdd(&s_qn[wave], 1u);
+                                if (at < QCAP) s_q[wave][at] = (row_in_tile << 16) | col_in_chunk;
+                            }
                         }
                     }
                 };
+                // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
+                // independent one every 32: tools/mfma_rate.hip)
 #pragma unroll
                 for (int rb = 0; rb < MF_RB; rb += 2) {
                     v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -333,7 +338,31 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
                     screen(acc1, rb + 1);
                 }
             }
+
+            // ---- complete this wave's candidates of the chunk exactly (outside the MFMA loop; wave-local, the LDS
+            // executes one wave's operations in order, so no barrier is needed between push, read and reset)
+            asm volatile("" ::: "memory");
+            const uint32_t nq = s_qn[wave];
+            if (nq != 0) {
+                if (nq <= QCAP) {
+                    for (uint32_t t = lane; t < nq; t += 64) {
+                        const uint32_t e = s_q[wave][t];
+                        const unsigned long long owner = row0 + (e >> 16), col = col0 + cbase + (e & 0xFFFFu);
+                        if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                    }
+                } else {
+                    // queue overflow (heavily duplicated data): every pair of this wave's rows and this chunk is completed exactly
+                    const uint32_t ccols = (ncols - cbase) < (uint32_t)CHUNK ? (ncols - cbase) : (uint32_t)CHUNK;
+                    for (uint32_t t = lane; t < (uint32_t)(32 * MF_RB) * ccols; t += 64) {
+                        const unsigned long long owner = row0 + wrow + t / ccols, col = col0 + cbase + t % ccols;
+                        if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                    }
+                }
+                asm volatile("" ::: "memory");
+                if (lane == 0) s_qn[wave] = 0;
+            }
         }
+        __syncthreads();  // the last chunk's buffers and queue are free before the next pass starts
     }
 }
 

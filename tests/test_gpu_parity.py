@@ -194,6 +194,21 @@ def test_all_pairs_sharded_over_parts(eng, oracle):
         assert merged == want and sum(len(p) for p in parts) == len(want)
 
 
+@pytest.mark.parametrize("thr", [0, 40, 70])
+def test_all_pairs_heavily_duplicated_data(eng, thr):
+    """thousands of identical hashes: every pair of a chunk is a candidate, the MFMA kernel's candidate queue overflows
+    and its exhaustive fallback must still report every pair exactly once"""
+    n = 2100
+    h = np.tile(np.arange(32, dtype=np.uint8) * 7, (n, 1))
+    h[n - 100:, 0] ^= 0xFF          # a second cluster at distance 8 from the first
+    e = eng.hamming_all_pairs(h, thr, cap=n * n // 2)
+    a, b = n - 100, 100
+    want = a * (a - 1) // 2 + b * (b - 1) // 2 + (a * b if thr >= 8 else 0)
+    assert len(e) == want and (e["i"] < e["j"]).all()
+    assert len({(int(x["i"]), int(x["j"])) for x in e}) == want
+    assert set(np.unique(e["d"]).tolist()) == ({0, 8} if thr >= 8 else {0})
+
+
 def test_all_pairs_edge_cases(eng):
     assert len(eng.hamming_all_pairs(np.zeros((0, 32), np.uint8), 10)) == 0
     assert len(eng.hamming_all_pairs(np.zeros((1, 32), np.uint8), 10)) == 0
