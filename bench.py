@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--hamming-steps", type=int, default=0, help="default: same as --steps")
     ap.add_argument("--pdq-kernel", type=int, default=1, help="1 = fused, 64-px strips (default), 2 = fused, 128-px strips, 0 = generic multi-pass")
     ap.add_argument("--hamming-kernel", type=int, default=1, help="1 = int8 MFMA fast path (default), 0 = VALU xor + popcount")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal: ranks may "
+                    "share one GPU, collectives are staged through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline leg")
     args = ap.parse_args()
@@ -63,13 +65,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsal on fewer GPUs than ranks
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     from rupphash_amd import EDGE_DTYPE, Engine
 
@@ -92,7 +99,7 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -146,7 +153,12 @@ def main():
         # exchange step: every rank contributes its shard of hashes (in a real scan: the hashes it just computed)
         eng.synth_hashes_dev(mine.data_ptr(), rank * shard, shard, n_h, n_clusters=n_clusters, stream=stream)
         if dist is not None:
-            dist.all_gather_into_tensor(all_h, mine)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(all_h, mine)  # the one exchange step of the path: RCCL all-gather of hash shards
+            else:
+                host = torch.empty((n_h, 32), dtype=torch.uint8)
+                dist.all_gather_into_tensor(host, mine.cpu())
+                all_h.copy_(host)
         d_count.zero_()
         eng.hamming_all_pairs_dev(all_h.data_ptr(), n_h, args.threshold, d_edges.data_ptr(), cap, d_count.data_ptr(),
                                   part=rank, nparts=world, stream=stream)
@@ -168,7 +180,7 @@ def main():
     n_edges_local = int(d_count.item())
     n_edges = n_edges_local
     if dist is not None:
-        t = torch.tensor([n_edges_local], dtype=torch.int64, device=dev)
+        t = torch.tensor([n_edges_local], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t)
         n_edges = int(t.item())
     expected_edges = n_clusters * 10 + (1 if n_h >= 10 else 0)
@@ -246,6 +258,35 @@ def main():
                                 "extrapolated_s_for_all_queries": n_h / q_rate,
                                 "sample": f"MIHIndex::new on all {n_h} hashes + the first {q_pilot} queries of find_groups "
                                           f"(max_dist {args.threshold}), {cores} threads"}}
+
+    # ------------------------------------------------------------------ the reference's own published cases (rank 0, N = 1)
+    if rank == 0 and world == 1:
+        rng = np.random.default_rng(1)
+        # (1) hamminghash.rs:336-412 / NOTES.txt:19: find_groups over 1M random u64 + an injected 5-cluster, max_dist 5
+        h64 = rng.integers(0, 2**64, 1_000_000, dtype=np.uint64)
+        target = 0xABCD_1234_5678_90EF
+        for v, i in zip([target, target ^ 1, target ^ 2, target ^ 0x8000, target ^ 0x8001], rng.choice(len(h64), 5, replace=False)):
+            h64[i] = v
+        eng.find_groups64(h64[:4096], 5)  # warm-up
+        t0 = time.perf_counter()
+        g64 = eng.find_groups64(h64, 5)
+        t_u64 = time.perf_counter() - t0
+        # (2) README.md:13: grouping 500 000 files (PDQ, 8 dihedral variants, default similarity 40)
+        nf = 500_000
+        coeffs = rng.normal(0, 20, (nf, 256)).astype(np.float32)
+        coeffs[1::1000] = coeffs[0::1000][: len(coeffs[1::1000])] + rng.normal(0, 0.5, (len(coeffs[1::1000]), 256)).astype(np.float32)
+        fh, _ = eng.pdq_hashes_from_coeffs(coeffs, want_hash=True, want_dihedral=False)
+        qual = np.full(nf, 100, np.int32)
+        t0 = time.perf_counter()
+        groups, cmp_count = eng.group_files_pdq(fh, 40, coeffs=coeffs, quality=qual)
+        t_group = time.perf_counter() - t0
+        result["reference_cases"] = {
+            "find_groups_1M_u64_max_dist_5": {"seconds": t_u64, "groups": len(g64), "includes": "H2D copy, all-pairs sweep, host greedy clustering",
+                                              "reference_published_seconds": 12.27, "reference_source": "NOTES.txt:19 (14 threads, unstated CPU)"},
+            "group_500k_files_pdq_similarity_40": {"seconds": t_group, "groups": len(groups), "comparison_count": int(cmp_count),
+                                                   "includes": "8 dihedral variants per file from coefficients, variant sweep, union-find",
+                                                   "reference_published_seconds": "15-20", "reference_source": "README.md:13 (unstated CPU)"},
+        }
 
     if rank == 0:
         print(json.dumps(result))

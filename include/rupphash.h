@@ -181,6 +181,14 @@ int rph_hamming_variant_pairs_dev(rph_ctx *ctx, const void *d_variants, uint32_t
  */
 int rph_find_groups256(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t max_dist,
                        uint32_t *members, uint32_t *offsets, uint32_t *n_groups_out);
+/* impl HammingHash for u64 (hamminghash.rs:23-41): all-pairs sweep over 64-bit hashes (pHash) and find_groups::<u64>
+ * (8 chunks of 8 bits, chunk tolerance max_dist / 8), same edge / group conventions as the 256-bit forms. */
+int rph_hamming_all_pairs64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, uint32_t threshold, uint32_t part,
+                            uint32_t nparts, rph_edge *edges, uint64_t cap, uint64_t *n_edges_out);
+int rph_hamming_all_pairs64_dev(rph_ctx *ctx, const void *d_hashes64, uint64_t n, uint32_t threshold, uint32_t part,
+                                uint32_t nparts, void *d_edges, uint64_t cap, void *d_count, void *stream);
+int rph_find_groups64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, uint32_t max_dist, uint32_t *members,
+                      uint32_t *offsets, uint32_t *n_groups_out);
 /* Same from a precomputed edge list (e.g. gathered from several GPUs). */
 int rph_find_groups_from_edges(const rph_edge *edges, uint64_t n_edges, uint64_t n,
                                uint32_t *members, uint32_t *offsets, uint32_t *n_groups_out);

@@ -66,6 +66,10 @@ SIGNATURES = {
     "rph_hamming_variant_pairs_dev": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32,
                                                 C.c_uint32, _vp, C.c_uint64, _vp, _vp]),
     "rph_find_groups256": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_uint32, _u32p, _u32p, C.POINTER(C.c_uint32)]),
+    "rph_hamming_all_pairs64": (C.c_int, [_vp, _u64p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64,
+                                          C.POINTER(C.c_uint64)]),
+    "rph_hamming_all_pairs64_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, _vp]),
+    "rph_find_groups64": (C.c_int, [_vp, _u64p, C.c_uint64, C.c_uint32, _u32p, _u32p, C.POINTER(C.c_uint32)]),
     "rph_find_groups_from_edges": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u32p, _u32p, C.POINTER(C.c_uint32)]),
     "rph_group_files_pdq": (C.c_int, [_vp, _u8p, _f32p, _u8p, _i32p, C.c_uint64, C.c_uint32, _u32p, _u32p,
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),

@@ -366,6 +366,76 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 64-bit hashes (impl HammingHash for u64, hamminghash.rs:23-41): the same tiled sweep, 2 dwords per hash
+// ---------------------------------------------------------------------------------------------
+struct Sweep64Args {
+    const uint2 *hashes;  // [n] little-endian u64 as (lo, hi)
+    unsigned long long n;
+    uint32_t threshold, mih_tol, part, nparts, n_tiles;
+    unsigned long long n_tile_pairs;
+    rph_edge *edges;
+    unsigned long long cap;
+    unsigned long long *count;
+};
+
+__global__ void __launch_bounds__(256) hamming64_sweep_kernel(Sweep64Args a)
+{
+    __shared__ uint2 s_cols[T_FILES];  // 8 KiB
+    const unsigned long long p = (unsigned long long)a.part + (unsigned long long)blockIdx.x * a.nparts;
+    if (p >= a.n_tile_pairs) return;
+    uint32_t I, J;
+    tile_pair(p, a.n_tiles, I, J);
+    const unsigned long long col0 = (unsigned long long)J * T_FILES, row0 = (unsigned long long)I * T_FILES;
+    const uint32_t ncols = (uint32_t)((a.n - col0) < (unsigned long long)T_FILES ? (a.n - col0) : T_FILES);
+    for (uint32_t t = threadIdx.x; t < T_FILES; t += 256) s_cols[t] = t < ncols ? a.hashes[col0 + t] : make_uint2(0, 0);
+    __syncthreads();
+    constexpr int R64 = T_FILES / 256;  // 4 rows per lane
+    uint2 rw[R64];
+#pragma unroll
+    for (int r = 0; r < R64; r++) {
+        const unsigned long long owner = row0 + (unsigned long long)r * 256 + threadIdx.x;
+        rw[r] = a.hashes[owner < a.n ? owner : 0];
+    }
+    for (uint32_t c = 0; c < ncols; c++) {
+        const uint2 cv = s_cols[c];
+        uint32_t dmin = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < R64; r++) {
+            const uint32_t d = bcnt_acc(rw[r].y ^ cv.y, bcnt_acc(rw[r].x ^ cv.x, 0));
+            dmin = d < dmin ? d : dmin;
+        }
+        if (dmin <= a.threshold) {
+#pragma unroll 1
+            for (int r = 0; r < R64; r++) {
+                const unsigned long long owner = row0 + (unsigned long long)r * 256 + threadIdx.x, col = col0 + c;
+                if (owner >= a.n || col <= owner) continue;  // i < j only (hamminghash.rs:216)
+                const uint2 rv = a.hashes[owner];
+                const uint32_t x0 = rv.x ^ cv.x, x1 = rv.y ^ cv.y;
+                const uint32_t d = (uint32_t)__builtin_popcount(x0) + (uint32_t)__builtin_popcount(x1);
+                if (d > a.threshold) continue;
+                // find_groups reachability for u64: 8 chunks of 8 bits (hamminghash.rs:24-31), first chunk with popcount <= tol
+                uint32_t flags = 0;
+                for (int k = 7; k >= 0; k--) {
+                    const uint32_t c8 = ((k < 4 ? x0 : x1) >> ((k & 3) * 8)) & 0xFFu;
+                    const uint32_t pc = (uint32_t)__builtin_popcount(c8);
+                    if (pc <= a.mih_tol) flags = RPH_EDGE_MIH_R1 | ((uint32_t)k << 5) | (pc == 0 ? 0u : 1u + (uint32_t)__builtin_ctz(c8));
+                }
+                const unsigned long long at = atomicAdd(a.count, 1ull);
+                if (at < a.cap) {
+                    rph_edge e;
+                    e.i = (uint32_t)owner;
+                    e.j = (uint32_t)col;
+                    e.d = (uint16_t)d;
+                    e.flags = (uint16_t)flags;
+                    a.edges[at] = e;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
@@ -432,3 +502,30 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
     return RPH_OK;
 }
 
+
+int rph_launch_hamming64_sweep(const uint64_t *d_hashes, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts,
+                               rph_edge *d_edges, uint64_t cap, unsigned long long *d_count, hipStream_t stream)
+{
+    if (nparts == 0 || part >= nparts || n > 0xFFFFFFFFull) {
+        rph_set_error("hamming64 sweep: bad arguments");
+        return RPH_ERR_INVALID_ARG;
+    }
+    if (n < 2) return RPH_OK;
+    Sweep64Args a;
+    a.hashes = reinterpret_cast<const uint2 *>(d_hashes);
+    a.n = n;
+    a.threshold = threshold > 64 ? 64 : threshold;
+    a.mih_tol = (threshold / 8u) >= 1 ? 1 : 0;  // chunk_tolerance = max_dist / NUM_CHUNKS (hamminghash.rs:193), NUM_CHUNKS = 8
+    a.part = part;
+    a.nparts = nparts;
+    a.n_tiles = (uint32_t)((n + T_FILES - 1) / T_FILES);
+    a.n_tile_pairs = (unsigned long long)a.n_tiles * (a.n_tiles + 1ull) / 2ull;
+    a.edges = d_edges;
+    a.cap = cap;
+    a.count = d_count;
+    const unsigned long long mine = (a.n_tile_pairs > part) ? (a.n_tile_pairs - part + nparts - 1) / nparts : 0;
+    if (mine == 0) return RPH_OK;
+    hipLaunchKernelGGL(hamming64_sweep_kernel, dim3((unsigned)mine), dim3(256), 0, stream, a);
+    RPH_HIP_CHECK(hipGetLastError());
+    return RPH_OK;
+}

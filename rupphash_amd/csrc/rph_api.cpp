@@ -373,6 +373,66 @@ int rph_hamming_variant_pairs(rph_ctx *ctx, const uint8_t *variants, uint32_t n_
                       n_edges_out);
 }
 
+int rph_hamming_all_pairs64_dev(rph_ctx *ctx, const void *d_hashes64, uint64_t n, uint32_t threshold, uint32_t part,
+                                uint32_t nparts, void *d_edges, uint64_t cap, void *d_count, void *stream)
+{
+    if (!ctx || (!d_hashes64 && n) || !d_count || (!d_edges && cap)) {
+        rph_set_error("rph_hamming_all_pairs64: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    return rph_launch_hamming64_sweep((const uint64_t *)d_hashes64, n, threshold, part, nparts, (rph_edge *)d_edges, cap,
+                                      (unsigned long long *)d_count, pick(ctx, stream));
+}
+
+int rph_hamming_all_pairs64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, uint32_t threshold, uint32_t part,
+                            uint32_t nparts, rph_edge *edges, uint64_t cap, uint64_t *n_edges_out)
+{
+    if (!ctx || (!hashes64 && n) || !n_edges_out || (!edges && cap)) {
+        rph_set_error("rph_hamming_all_pairs64: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    *n_edges_out = 0;
+    if (n < 2) return RPH_OK;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    DevBuf d_h, d_e, d_cnt;
+    RPH_TRY(d_h.alloc(n * 8));
+    RPH_TRY(d_e.alloc(cap * sizeof(rph_edge)));
+    RPH_TRY(d_cnt.alloc(8));
+    RPH_HIP_CHECK(hipMemcpyAsync(d_h.p, hashes64, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    RPH_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, 8, ctx->stream));
+    RPH_TRY(rph_launch_hamming64_sweep((const uint64_t *)d_h.p, n, threshold, part, nparts, (rph_edge *)d_e.p, cap,
+                                       (unsigned long long *)d_cnt.p, ctx->stream));
+    unsigned long long cnt = 0;
+    RPH_HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *n_edges_out = cnt;
+    const uint64_t take = std::min<uint64_t>(cnt, cap);
+    if (take) RPH_HIP_CHECK(hipMemcpy(edges, d_e.p, take * sizeof(rph_edge), hipMemcpyDeviceToHost));
+    if (cnt > cap) {
+        rph_set_error("hamming64 sweep: %llu edges found, capacity %llu", cnt, (unsigned long long)cap);
+        return RPH_ERR_CAPACITY;
+    }
+    return RPH_OK;
+}
+
+int rph_find_groups64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, uint32_t max_dist, uint32_t *members,
+                      uint32_t *offsets, uint32_t *n_groups_out)
+{
+    if (!ctx || (!hashes64 && n) || !members || !offsets || !n_groups_out) {
+        rph_set_error("rph_find_groups64: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    *n_groups_out = 0;
+    offsets[0] = 0;
+    if (n < 2) return RPH_OK;
+    std::vector<rph_edge> edges;
+    RPH_TRY(sweep_growing(n, edges, [&](rph_edge *e, uint64_t cap, uint64_t *found) {
+        return rph_hamming_all_pairs64(ctx, hashes64, n, max_dist, 0, 1, e, cap, found);
+    }));
+    return rph_host_find_groups(edges.data(), edges.size(), n, members, offsets, n_groups_out);
+}
+
 int rph_find_groups_from_edges(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,
                                uint32_t *n_groups_out)
 {

@@ -42,6 +42,8 @@ int rph_launch_pdq_from_coeffs(const float *d_coeffs, uint32_t n, uint8_t *d_has
 int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
                              const uint8_t *d_has_features, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts, rph_edge *d_edges,
                              uint64_t cap, unsigned long long *d_count, hipStream_t stream, int use_mfma);
+int rph_launch_hamming64_sweep(const uint64_t *d_hashes, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts,
+                               rph_edge *d_edges, uint64_t cap, unsigned long long *d_count, hipStream_t stream);
 int rph_launch_mih_build256(rph_ctx *ctx, const uint8_t *d_hashes, uint64_t n, uint32_t *d_offsets, uint32_t *d_values,
                             hipStream_t stream);
 // synth_kernels.hip

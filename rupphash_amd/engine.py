@@ -154,6 +154,34 @@ class Engine:
               "rph_find_groups256")
         return self._groups(members, offsets, ng.value)
 
+    def hamming_all_pairs64(self, hashes, threshold, part=0, nparts=1, cap=None):
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        n = len(hashes)
+        cap = max(1 << 16, 4 * n) if cap is None else cap
+        while True:
+            edges = np.zeros(cap, EDGE_DTYPE)
+            found = C.c_uint64()
+            rc = self.L.rph_hamming_all_pairs64(self.ctx, _ptr(hashes), n, threshold, part, nparts, _ptr(edges), cap, C.byref(found))
+            if rc == _lib.RPH_ERR_CAPACITY:
+                cap = int(found.value) + 1024
+                continue
+            check(rc, "rph_hamming_all_pairs64")
+            return edges[: found.value]
+
+    def hamming_all_pairs64_dev(self, d_hashes, n, threshold, d_edges, cap, d_count, part=0, nparts=1, stream=None):
+        check(self.L.rph_hamming_all_pairs64_dev(self.ctx, d_hashes, n, threshold, part, nparts, d_edges, cap, d_count, stream),
+              "rph_hamming_all_pairs64_dev")
+
+    def find_groups64(self, hashes, max_dist):
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        n = len(hashes)
+        members = np.zeros(max(n, 1), np.uint32)
+        offsets = np.zeros(n // 2 + 2, np.uint32)
+        ng = C.c_uint32()
+        check(self.L.rph_find_groups64(self.ctx, _ptr(hashes), n, max_dist, _ptr(members), _ptr(offsets), C.byref(ng)),
+              "rph_find_groups64")
+        return self._groups(members, offsets, ng.value)
+
     def find_groups_from_edges(self, edges, n):
         edges = np.ascontiguousarray(edges, EDGE_DTYPE)
         members = np.zeros(max(n, 1), np.uint32)

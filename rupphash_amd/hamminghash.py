@@ -104,6 +104,24 @@ class SparseBitSet:
         self.dirty.clear()
 
 
+class MIHIndex64:
+    """MIHIndex<u64>: only what find_groups::<u64> needs (the hashes); the sweep replaces the probe tables."""
+
+    def __init__(self, hashes, engine=None):
+        self.engine = engine or default_engine()
+        self.db_hashes = np.ascontiguousarray(hashes, np.uint64)
+
+    def hash(self, dense_id):
+        return int(self.db_hashes[int(dense_id)])
+
+    def len(self):
+        return len(self.db_hashes)
+
+    __len__ = len
+
+
 def find_groups(index, max_dist):
-    """find_groups::<[u8;32]>, bit-exact including member order."""
+    """find_groups::<[u8;32]> / find_groups::<u64>, bit-exact including member order."""
+    if isinstance(index, MIHIndex64):
+        return index.engine.find_groups64(index.db_hashes, max_dist)
     return index.engine.find_groups256(index.db_hashes, max_dist)

@@ -440,3 +440,46 @@ def test_fused512_equals_generic_on_4096_images(eng):
     for k in range(123_000, 123_000 + n):
         if k % 1000 == 999 and k - 1 >= 123_000:
             assert hh.hamming_distance(h[k - 123_000], h[k - 1 - 123_000]) <= 16
+
+
+# ------------------------------------------------------------------ 64-bit hashes (impl HammingHash for u64)
+def test_u64_reference_tests_on_gpu(eng, oracle):
+    """hamminghash.rs:286-307 ({0, 0xFFF} at 12 -> [[0, 1]]) and :336-412 (injected 5-cluster, max_dist 5) at the full 1M."""
+    from rupphash_amd import hamminghash as hh
+
+    assert hh.find_groups(hh.MIHIndex64(np.array([0, 0xFFF], np.uint64), eng), 12) == [[0, 1]]
+    n = 1_000_000
+    rng = np.random.default_rng(2024)
+    hashes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    target = 0xABCD_1234_5678_90EF
+    idx = rng.choice(n, 5, replace=False)
+    for v, i in zip([target, target ^ 1, target ^ 2, target ^ 0x8000, target ^ 0x8001], idx):
+        hashes[i] = v
+    groups = hh.find_groups(hh.MIHIndex64(hashes, eng), 5)
+    g = [g for g in groups if int(idx[0]) in g]
+    assert g and set(int(i) for i in idx) <= set(g[0])
+
+
+@pytest.mark.parametrize("thr", [0, 5, 7, 8, 12, 15, 20])
+def test_u64_find_groups_and_edges_match_oracle(eng, oracle, thr):
+    rng = np.random.default_rng(600 + thr)
+    n = 3000
+    hashes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    for c in range(60):
+        base = int(rng.integers(0, 2**63))
+        for j in rng.choice(n, 4, replace=False):
+            v = base
+            for b in rng.choice(64, rng.integers(0, 14), replace=False):
+                v ^= 1 << int(b)
+            hashes[j] = v
+    edges = eng.hamming_all_pairs64(hashes, thr)
+    brute = []
+    h = hashes
+    x = h[:, None] ^ h[None, :]
+    pc = np.zeros(x.shape, np.uint8)
+    for s in range(64):
+        pc += ((x >> np.uint64(s)) & np.uint64(1)).astype(np.uint8)
+    ii, jj = np.nonzero(np.triu(pc <= thr, k=1))
+    brute = sorted((int(i), int(j), int(pc[i, j])) for i, j in zip(ii, jj))
+    assert edge_set(edges) == brute
+    assert eng.find_groups64(hashes, thr) == oracle.find_groups(oracle.KIND_U64, hashes, thr)
