@@ -36,7 +36,7 @@ typedef enum rph_status {
     RPH_ERR_NO_DEVICE = -2,     /* no HIP device / not gfx950 */
     RPH_ERR_HIP = -3,           /* a HIP runtime call failed; rph_last_error() has the text */
     RPH_ERR_OOM = -4,
-    RPH_ERR_UNSUPPORTED = -5,   /* e.g. w or h > 512: pre-downsample (pdqhash.rs:181-220) not built yet */
+    RPH_ERR_UNSUPPORTED = -5,   /* reserved */
     RPH_ERR_CAPACITY = -6       /* output capacity too small; the required count is still reported */
 } rph_status;
 
@@ -81,8 +81,10 @@ int rph_synchronize(rph_ctx *ctx);
  *   coeffs_out   n x 256 floats         PdqFeatures.coefficients, row-major i*16+j
  *   dihedral_out n x 8 x 32 bytes       generate_dihedral_hashes(), reference slot order
  *   valid_out    n bytes                1 = Some(..), 0 = None (w or h < 5, :167-169)
- * w or h > 512 needs the reference's pre-downsample (third-party
- * fast_image_resize, :181-220): not built yet -> RPH_ERR_UNSUPPORTED.
+ * w or h > 512: the images are first converted to luma and pre-downsampled to the aspect-preserving <= 512 px
+ * thumbnail exactly where the reference does it (:181-220, calculate_target_dimensions + resize_luma_fast).  The
+ * resize is the third-party fast_image_resize 6.1.0 Convolution(Box)/U8, restated from its published algorithm:
+ * parity with the Rust binary is unpinned for such inputs.
  */
 int rph_pdq_hash_batch(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, uint32_t h,
                        uint32_t channels, size_t row_stride, size_t image_stride,

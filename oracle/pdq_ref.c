@@ -21,8 +21,8 @@
  *   - rows with no reference fixture (to_luma601, jarosz box filter, decimate)
  *     are line-by-line restatements: "parity unpinned" for those rows.
  *   - the >512 px pre-downsample (fast_image_resize 6.1.0, third party, source
- *     absent from /root/reference) is NOT restated: rph_ref_pdq_* return
- *     RPH_REF_NEEDS_RESIZE for such inputs.
+ *     absent from /root/reference) is restated from its published algorithm in
+ *     resize_ref.c: "parity unpinned" for every input with a side > 512 px.
  *   - the DCT table depends on the platform cosf (Rust f32::cos -> libm cosf);
  *     this oracle calls glibc cosf at run time like the reference does.
  */
@@ -43,7 +43,10 @@
 
 #define RPH_REF_OK 0
 #define RPH_REF_TOO_SMALL 1     /* generate_pdq_features -> None, pdqhash.rs:167-169 */
-#define RPH_REF_NEEDS_RESIZE 2  /* w or h > 512: third-party resize not restated */
+#define RPH_REF_NEEDS_RESIZE 2  /* kept for ABI stability; no longer returned */
+
+void rph_ref_resize_box_u8(const uint8_t *src, uint32_t w, uint32_t h, uint8_t *dst, uint32_t nw, uint32_t nh); /* resize_ref.c */
+void rph_ref_target_dimensions(uint32_t w, uint32_t h, uint32_t max_dim, uint32_t *ow, uint32_t *oh);
 
 /* ---- DCT matrix: pdqhash.rs:287-304 (compute_dct_matrix) ---- */
 static float g_dct[DCT_OUTPUT_W_H][BUFFER_W_H];
@@ -399,8 +402,8 @@ void rph_ref_features_from_buffer64(const float *buf64, float *coeffs)
 int rph_ref_pdq_from_luma(const uint8_t *luma, int w, int h, float *coeffs, float *quality,
                           float *buf64_out)
 {
-    if (w < MIN_HASHABLE_DIM || h < MIN_HASHABLE_DIM) return RPH_REF_TOO_SMALL;
-    if (w > DOWNSAMPLE_DIMS || h > DOWNSAMPLE_DIMS) return RPH_REF_NEEDS_RESIZE;
+    /* no size check here: the reference checks MIN_HASHABLE_DIM once, before the resize (pdqhash.rs:167), so a
+     * 4000x5 input is hashed from its 512x1 thumbnail */
     size_t n = (size_t)w * (size_t)h;
     float *buf = (float *)malloc(n * sizeof(float));
     float *tmp = (float *)malloc(n * sizeof(float));
@@ -425,13 +428,23 @@ int rph_ref_pdq_features(const uint8_t *px, int w, int h, int stride_bytes, int 
                          float *coeffs, float *quality)
 {
     if (w < MIN_HASHABLE_DIM || h < MIN_HASHABLE_DIM) return RPH_REF_TOO_SMALL;
-    if (w > DOWNSAMPLE_DIMS || h > DOWNSAMPLE_DIMS) return RPH_REF_NEEDS_RESIZE;
     uint8_t *luma = (uint8_t *)malloc((size_t)w * (size_t)h);
     if (channels == 1) {
         for (int y = 0; y < h; y++)
             memcpy(luma + (size_t)y * w, px + (size_t)y * stride_bytes, (size_t)w);
     } else {
         rph_ref_luma601(px, w, h, stride_bytes, channels, luma);
+    }
+    /* Resize if larger than 512x512 (pdqhash.rs:181-191): the 1-channel luma image is resized, aspect preserved */
+    if (w > DOWNSAMPLE_DIMS || h > DOWNSAMPLE_DIMS) {
+        uint32_t nw, nh;
+        rph_ref_target_dimensions((uint32_t)w, (uint32_t)h, DOWNSAMPLE_DIMS, &nw, &nh);
+        uint8_t *small = (uint8_t *)malloc((size_t)nw * nh);
+        rph_ref_resize_box_u8(luma, (uint32_t)w, (uint32_t)h, small, nw, nh);
+        free(luma);
+        luma = small;
+        w = (int)nw;
+        h = (int)nh;
     }
     int rc = rph_ref_pdq_from_luma(luma, w, h, coeffs, quality, NULL);
     free(luma);

@@ -237,12 +237,9 @@ int rph_pdq_hash_batch_dev(rph_ctx *ctx, const void *d_px, uint32_t n, uint32_t 
         if (d_valid) RPH_HIP_CHECK(hipMemsetAsync(d_valid, 0, n, s));
         return RPH_OK;
     }
-    if (w > RPH_PDQ_MAX_DIM || h > RPH_PDQ_MAX_DIM) {
-        rph_set_error("rph_pdq_hash_batch: %ux%u needs the reference's >512 px pre-downsample "
-                      "(fast_image_resize, pdqhash.rs:181-220), which is not built yet",
-                      w, h);
-        return RPH_ERR_UNSUPPORTED;
-    }
+    if (w > RPH_PDQ_MAX_DIM || h > RPH_PDQ_MAX_DIM)  // pre-downsample to the <= 512 px thumbnail first (pdqhash.rs:181-191)
+        return rph_launch_pdq_resized(ctx, (const uint8_t *)d_px, n, w, h, channels, row_stride, image_stride, (uint8_t *)d_hash32,
+                                      (float *)d_quality, (float *)d_coeffs, (uint8_t *)d_dihedral, (uint8_t *)d_valid, s);
     if (ctx->pdq_kernel >= 1 && w == 512 && h == 512 && channels == 3 && (row_stride % 4) == 0 && (image_stride % 4) == 0 &&
         ((uintptr_t)d_px % 4) == 0) {
         int rc = rph_launch_pdq_fused512(ctx, (const uint8_t *)d_px, n, row_stride, image_stride, (uint8_t *)d_hash32,

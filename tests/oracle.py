@@ -186,6 +186,14 @@ def pdq_batch_rgb(imgs, want_coeffs=False):
     return (hashes, qual, coeffs) if want_coeffs else (hashes, qual)
 
 
+def resize_box_u8(luma, nw, nh):
+    luma = np.ascontiguousarray(luma, np.uint8)
+    h, w = luma.shape
+    out = np.zeros((nh, nw), np.uint8)
+    lib().rph_ref_resize_box_u8(_p(luma), C.c_uint32(w), C.c_uint32(h), _p(out), C.c_uint32(nw), C.c_uint32(nh))
+    return out
+
+
 def jarosz(plane, w_rows, w_cols, nreps=2):
     buf = np.array(plane, np.float32, copy=True, order="C")
     tmp = np.zeros_like(buf)

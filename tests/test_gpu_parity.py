@@ -111,9 +111,36 @@ def test_pdq_none_and_unsupported(eng):
     assert not out["valid"].any() and not out["hash"].any()
     assert pdqhash.generate_pdq(np.zeros((64, 4, 3), np.uint8), eng) is None        # pdqhash.rs:167-169
     assert pdqhash.generate_pdq_features(np.zeros((5, 5, 3), np.uint8), eng) is not None
-    with pytest.raises(RphError) as e:
-        eng.pdq_hash_batch(np.zeros((1, 513, 16, 3), np.uint8))
-    assert e.value.status == -5
+    assert eng.pdq_hash_batch(np.zeros((1, 513, 16, 3), np.uint8))["valid"][0] == 1   # > 512: resized, then hashed
+
+
+RESIZED = [(780, 768, 3), (1280, 854, 3), (513, 512, 3), (512, 513, 1), (4000, 5, 3), (5, 4000, 3), (1024, 1024, 4), (600, 600, 1),
+           (2048, 1536, 3)]
+
+
+@pytest.mark.parametrize("w,h,ch", RESIZED)
+def test_pdq_with_predownsample_matches_oracle(eng, oracle, w, h, ch):
+    """pdqhash.rs:181-220: sides > 512 px go through luma -> box-convolution thumbnail -> PDQ.  GPU == oracle bit for bit
+    (the resize itself is a restatement of third-party code: parity unpinned against the Rust binary)."""
+    rng = np.random.default_rng(w * 7 + h)
+    n = 2
+    shape = (n, h, w) if ch == 1 else (n, h, w, ch)
+    imgs = rng.integers(0, 256, shape, dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    grad = ((xx * 200) // max(w - 1, 1) + (yy * 55) // max(h - 1, 1)).astype(np.uint8)
+    if ch == 1:
+        imgs[0] = grad
+    else:
+        imgs[0, ..., 0] = grad
+        imgs[0, ..., 1] = grad[::-1]
+    out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
+    for k in range(n):
+        rc, coeffs, q = oracle.pdq_features(imgs[k])
+        assert rc == 0 and out["valid"][k] == 1
+        assert np.array_equal(bits(out["coeffs"][k]), bits(coeffs)), k
+        assert bits(out["quality"][k:k + 1])[0] == bits(np.float32(q))[()]
+        assert np.array_equal(out["hash"][k], oracle.to_hash(coeffs))
+        assert np.array_equal(out["dihedral"][k], oracle.dihedral_hashes(coeffs))
 
 
 def lcg_features(seed):

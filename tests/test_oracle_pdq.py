@@ -94,11 +94,36 @@ def test_target_dimensions_never_collapse_to_zero(oracle):
 
 
 def test_min_hashable_dim_and_resize_gate(oracle):
-    """pdqhash.rs:17,167-169 (None below 5 px) and :181 (resize gate, not restated)."""
+    """pdqhash.rs:17,167-169 (None below 5 px, checked once, BEFORE the resize) and :181 (resize gate)."""
     assert oracle.pdq_features(np.zeros((4, 64, 3), np.uint8))[0] == oracle.REF_TOO_SMALL
     assert oracle.pdq_features(np.zeros((64, 4, 3), np.uint8))[0] == oracle.REF_TOO_SMALL
     assert oracle.pdq_features(np.zeros((5, 5, 3), np.uint8))[0] == oracle.REF_OK
-    assert oracle.pdq_features(np.zeros((513, 8, 3), np.uint8))[0] == oracle.REF_NEEDS_RESIZE
+    assert oracle.pdq_features(np.zeros((513, 8, 3), np.uint8))[0] == oracle.REF_OK     # resized to 512 x 7
+    assert oracle.pdq_features(np.zeros((5, 4000, 3), np.uint8))[0] == oracle.REF_OK    # 4000 x 5 -> 512 x 1, still hashed
+
+
+def test_resize_restatement_properties(oracle):
+    """resize_ref.c restates fast_image_resize 6.1.0 Convolution(Box)/U8 from its published algorithm (PARITY UNPINNED: the
+    crate's source is absent).  What can be checked here: exact integer ratios are plain rounded box means, constants stay
+    constant, and the result stays within one grey level of Pillow's BOX resample (same algorithm family; Pillow carries
+    22-bit coefficients, the crate 16-bit ones at an adaptive precision, so single levels may differ)."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (1024, 1536), dtype=np.uint8)
+    r = oracle.resize_box_u8(a, 512, 512)                       # 3x horizontally, 2x vertically
+    h = (a.reshape(1024, 512, 3).astype(np.int64).sum(axis=2) * 2 + 3) // 6          # round(mean of 3), half up
+    v = (h.reshape(512, 2, 512).sum(axis=1) + 1) // 2                                  # round(mean of 2), half up
+    assert np.abs(r.astype(int) - v).max() <= 1   # fixed-point coefficients: at most one level off the exact means
+    assert (oracle.resize_box_u8(np.full((700, 900), 37, np.uint8), 512, 398) == 37).all()
+    from PIL import Image
+
+    # (geometries whose window edges never fall exactly on a pixel boundary: on exact ties, e.g. 517 -> 132 rows, the two
+    #  implementations evaluate the box filter argument with differently ordered f64 expressions and may disagree on
+    #  whether the edge pixel is inside -- one more reason this step is unpinned)
+    for (w, h_) in [(780, 768), (1280, 854), (513, 600), (2000, 1111)]:
+        nw, nh = oracle.target_dimensions(w, h_)
+        img = rng.integers(0, 256, (h_, w), dtype=np.uint8)
+        pil = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BOX))
+        assert np.abs(oracle.resize_box_u8(img, nw, nh).astype(int) - pil.astype(int)).max() <= 1, (w, h_)
 
 
 def test_luma601_integer_formula(oracle):
