@@ -192,6 +192,8 @@ __global__ void __launch_bounds__(BLOCK) hamming_sweep_kernel(SweepArgs a)
 // ---------------------------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int MF_BLOCK = 256;   // 4 waves; wave w owns rows 256 w .. 256 w + 255 of the 1024-row tile
 
@@ -367,6 +369,174 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
 }
 
 
+// FP4 (e2m1) formulation: +1 = 0x2, -1 = 0xA, one v_mfma_scale_f32_32x32x64_f8f6f4 (scales 1.0) evaluates a 64-bit slice
+// of 32 x 32 pairs; f32 accumulation of +-1 products is exact.  PW (even) = prefix dwords.
+template <int PW>
+__global__ void __launch_bounds__(MF_BLOCK, 2) hamming_fp4_kernel(SweepArgs a)
+{
+    constexpr int NK = PW / 2;                // MFMAs (64-bit slices) per tile
+    constexpr int PITCH = PW * 16 + 16;      // bytes per column: [k-half h][slice][32 x fp4 = 16 B] + pad
+    constexpr int CHUNK = 256;  // columns expanded into LDS at a time (two buffers)
+    constexpr int QCAP = 256;                // candidate queue per wave and chunk; overflow falls back to an exhaustive completion
+    constexpr int MF_RB = 8;   // 32-row blocks per wave and pass (A fragments: MF_RB * PW * 4 VGPRs)
+    constexpr int PASS_ROWS = 4 * 32 * MF_RB; // rows one pass of the 4 waves covers; T_FILES / PASS_ROWS passes per tile
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * CHUNK * PITCH];
+    __shared__ uint32_t s_lut[256];     // byte -> 8 fp4 codes
+    __shared__ uint32_t s_q[4][QCAP];   // one queue per wave: filled and drained by the same wave, no barrier needed
+    __shared__ uint32_t s_qn[4];
+
+    const unsigned long long p = (unsigned long long)a.part + (unsigned long long)blockIdx.x * a.nparts;
+    if (p >= a.n_tile_pairs) return;
+    uint32_t I, J;
+    tile_pair(p, a.n_tiles, I, J);
+    const unsigned long long col0 = (unsigned long long)J * T_FILES;
+    const unsigned long long row0 = (unsigned long long)I * T_FILES;
+    const uint32_t ncols = (uint32_t)((a.n - col0) < (unsigned long long)T_FILES ? (a.n - col0) : T_FILES);
+
+    {
+        uint32_t e = 0;
+        for (int i = 0; i < 8; i++) e |= (((threadIdx.x >> i) & 1u) ? 0x2u : 0xAu) << (4 * i);
+        s_lut[threadIdx.x] = e;
+    }
+    if (threadIdx.x < 4) s_qn[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c32 = lane & 31, h = lane >> 5;
+    const float thresh_dot = (float)(32 * PW - 2 * (int)a.threshold);  // partial distance <= threshold  <=>  dot >= 32 PW - 2 threshold
+    const uint32_t nv = a.n_variants;
+
+    for (uint32_t vp = 0; vp < nv * (T_FILES / PASS_ROWS); vp++) {
+        const uint32_t v = vp / (T_FILES / PASS_ROWS);
+        const uint32_t wrow = (vp % (T_FILES / PASS_ROWS)) * PASS_ROWS + wave * 32 * MF_RB;  // first tile row of this wave in this pass
+        // A fragments: row block rb, slice ks: this lane (row c32, half h) holds the 32 bits of dword 2 ks + h of its row
+        v8i A[MF_RB][NK];
+#pragma unroll
+        for (int rb = 0; rb < MF_RB; rb++) {
+            const unsigned long long owner = row0 + wrow + 32ull * rb + c32;
+            const uint32_t *rp = a.rows + ((owner < a.n ? owner : 0ull) * nv + v) * 8;
+            uint32_t d[8];
+            const uint4 lo = *reinterpret_cast<const uint4 *>(rp);
+            d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w;
+            if (PW > 4) {
+                const uint4 hi = *reinterpret_cast<const uint4 *>(rp + 4);
+                d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
+            }
+#pragma unroll
+            for (int ks = 0; ks < NK; ks++) {
+                const uint32_t dw = h ? d[2 * ks + 1] : d[2 * ks];
+                A[rb][ks] = v8i{(int)s_lut[dw & 0xFFu], (int)s_lut[(dw >> 8) & 0xFFu], (int)s_lut[(dw >> 16) & 0xFFu], (int)s_lut[dw >> 24], 0, 0, 0, 0};
+            }
+        }
+
+        // column chunks are double buffered: the packed dwords of chunk i + 1 are fetched into registers while chunk i
+        // is swept and expanded into the other LDS buffer afterwards, so global latency never sits between two chunks
+        constexpr int PER_THREAD = (CHUNK * PW + MF_BLOCK - 1) / MF_BLOCK;
+        uint32_t pre[PER_THREAD];
+        auto fetch = [&](uint32_t cbase) {
+#pragma unroll
+            for (int q = 0; q < PER_THREAD; q++) {
+                const uint32_t t = threadIdx.x + q * MF_BLOCK;
+                const uint32_t col = t / PW, kb = t % PW;
+                pre[q] = (t < CHUNK * PW && cbase + col < ncols) ? a.cols[(col0 + cbase + col) * 8 + kb] : 0u;
+            }
+        };
+        auto expand = [&](uint32_t cbase, uint8_t *buf) {
+#pragma unroll
+            for (int q = 0; q < PER_THREAD; q++) {
+                const uint32_t t = threadIdx.x + q * MF_BLOCK;
+                if (t >= CHUNK * PW) continue;
+                const uint32_t col = t / PW, kb = t % PW;
+                const bool live = cbase + col < ncols;
+                // dword kb belongs to slice kb / 2, k-half kb & 1
+                uint8_t *dst = buf + col * PITCH + ((kb & 1) * NK + (kb >> 1)) * 16;
+                const uint32_t dw = pre[q];
+                uint4 e = make_uint4(s_lut[dw & 0xFFu], s_lut[(dw >> 8) & 0xFFu], s_lut[(dw >> 16) & 0xFFu], s_lut[dw >> 24]);
+                if (!live) e = make_uint4(0, 0, 0, 0);  // fp4 zeros: dot 0, never a candidate unless every pair is
+                *reinterpret_cast<uint4 *>(dst) = e;
+            }
+        };
+        fetch(0);
+        int which = 0;
+        for (uint32_t cbase = 0; cbase < ncols; cbase += CHUNK, which ^= 1) {
+            uint8_t *s_b = s_buf + which * (CHUNK * PITCH);
+            expand(cbase, s_b);
+            __syncthreads();  // chunk visible (and the queue reset of the previous chunk)
+            if (cbase + CHUNK < ncols) fetch(cbase + CHUNK);
+
+            // ---- fast path: MFMA + VALU screen only.  No global memory operation lives in this loop (candidates go to
+            // an LDS queue), so the compiler never has to drain vmcnt here and the prefetch above stays in flight.
+#pragma unroll 1
+            for (int cb = 0; cb < CHUNK / 32; cb++) {
+                if (cbase + cb * 32 >= ncols) break;
+                v8i B[NK];
+                const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * NK * 16;
+#pragma unroll
+                for (int ks = 0; ks < NK; ks++) {
+                    const v4i t = *reinterpret_cast<const v4i *>(bp + ks * 16);
+                    B[ks] = v8i{t[0], t[1], t[2], t[3], 0, 0, 0, 0};
+                }
+                auto screen = [&](const v16f &acc, int rb) {
+                    float m = acc[0];
+#pragma unroll
+                    for (int r = 1; r < 16; r++) m = acc[r] > m ? acc[r] : m;
+                    if (m >= thresh_dot) {  // rare
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            if (acc[r] >= thresh_dot) {
+                                // C/D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                                const uint32_t row_in_tile = wrow + 32u * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                const uint32_t col_in_chunk = cb * 32 + c32;
+                                const uint32_t at = atomicAdd(&s_qn[wave], 1u);
+                                if (at < QCAP) s_q[wave][at] = (row_in_tile << 16) | col_in_chunk;
+                            }
+                        }
+                    }
+                };
+                // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
+                // independent one every 32: tools/mfma_rate.hip)
+#pragma unroll
+                for (int rb = 0; rb < MF_RB; rb += 2) {
+                    v16f acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    v16f acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < NK; ks++) {  // cbsz = blgp = 4: fp4 e2m1; E8M0 scale 127 = 2^0
+                        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rb][ks], B[ks], acc0, 4, 4, 0, 127, 0, 127);
+                        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rb + 1][ks], B[ks], acc1, 4, 4, 0, 127, 0, 127);
+                    }
+                    screen(acc0, rb);
+                    screen(acc1, rb + 1);
+                }
+            }
+
+            // ---- complete this wave's candidates of the chunk exactly (outside the MFMA loop; wave-local, the LDS
+            // executes one wave's operations in order, so no barrier is needed between push, read and reset)
+            asm volatile("" ::: "memory");
+            const uint32_t nq = s_qn[wave];
+            if (nq != 0) {
+                if (nq <= QCAP) {
+                    for (uint32_t t = lane; t < nq; t += 64) {
+                        const uint32_t e = s_q[wave][t];
+                        const unsigned long long owner = row0 + (e >> 16), col = col0 + cbase + (e & 0xFFFFu);
+                        if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                    }
+                } else {
+                    // queue overflow (heavily duplicated data): every pair of this wave's rows and this chunk is completed exactly
+                    const uint32_t ccols = (ncols - cbase) < (uint32_t)CHUNK ? (ncols - cbase) : (uint32_t)CHUNK;
+                    for (uint32_t t = lane; t < (uint32_t)(32 * MF_RB) * ccols; t += 64) {
+                        const unsigned long long owner = row0 + wrow + t / ccols, col = col0 + cbase + t % ccols;
+                        if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                    }
+                }
+                asm volatile("" ::: "memory");
+                if (lane == 0) s_qn[wave] = 0;
+            }
+        }
+        __syncthreads();  // the last chunk's buffers and queue are free before the next pass starts
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // 64-bit hashes (impl HammingHash for u64, hamminghash.rs:23-41): the same tiled sweep, 2 dwords per hash
 // ---------------------------------------------------------------------------------------------
@@ -473,6 +643,17 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
     // Partial-width test: unrelated 256-bit hashes differ in ~16*PW +- sqrt(8*PW) of the first
     // 32*PW bits; keep ~5 sigma between that and the threshold.
     const dim3 grid((unsigned)mine), block(BLOCK);
+    if (use_mfma == 2) {
+        const dim3 mblock(MF_BLOCK);
+        if (a.threshold <= 36)
+            hipLaunchKernelGGL(hamming_fp4_kernel<4>, grid, mblock, 0, stream, a);
+        else if (a.threshold <= 60)
+            hipLaunchKernelGGL(hamming_fp4_kernel<6>, grid, mblock, 0, stream, a);
+        else
+            hipLaunchKernelGGL(hamming_fp4_kernel<8>, grid, mblock, 0, stream, a);
+        RPH_HIP_CHECK(hipGetLastError());
+        return RPH_OK;
+    }
     if (use_mfma) {
         const dim3 mblock(MF_BLOCK);
         if (a.threshold <= 36)

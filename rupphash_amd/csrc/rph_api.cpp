@@ -199,7 +199,7 @@ void *rph_stream(rph_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int rph_hamming_set_kernel(rph_ctx *ctx, int which)
 {
-    if (!ctx || which < 0 || which > 1) return RPH_ERR_INVALID_ARG;
+    if (!ctx || which < 0 || which > 2) return RPH_ERR_INVALID_ARG;
     ctx->hamming_kernel = which;
     return RPH_OK;
 }

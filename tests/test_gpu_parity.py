@@ -193,7 +193,7 @@ def test_dihedral_hashes_match_physically_transformed_image(eng, oracle):
 
 
 # ------------------------------------------------------------------ Hamming sweep
-@pytest.mark.parametrize("kernel", [1, 0])  # 1 = int8 MFMA fast path (default), 0 = VALU xor + popcount
+@pytest.mark.parametrize("kernel", [1, 0, 2])  # 1 = int8 MFMA fast path (default), 0 = VALU xor + popcount, 2 = fp4 MFMA
 @pytest.mark.parametrize("thr", [0, 10, 31, 32, 36, 37, 48, 49, 60, 61, 74, 75, 100, 200])
 def test_all_pairs_matches_brute_force(eng, oracle, thr, kernel):
     rng = np.random.default_rng(300 + thr)
@@ -204,7 +204,7 @@ def test_all_pairs_matches_brute_force(eng, oracle, thr, kernel):
     want = oracle.all_pairs256(hashes, thr)
     assert edge_set(got) == sorted(map(tuple, want.tolist()))
     if thr == 32:  # flags (find_groups reachability / probe slot) agree between the two formulations
-        eng.set_hamming_kernel(1 - kernel)
+        eng.set_hamming_kernel(0 if kernel else 1)
         other = eng.hamming_all_pairs(hashes, thr)
         eng.set_hamming_kernel(1)
         key = lambda e: sorted((int(x["i"]), int(x["j"]), int(x["d"]), int(x["flags"])) for x in e)
@@ -333,7 +333,7 @@ def test_mih_build_matches_reference_csr(eng, oracle):
 
 
 # ------------------------------------------------------------------ full-size, construction-known answers
-@pytest.mark.parametrize("kernel", [1, 0])
+@pytest.mark.parametrize("kernel", [1, 0, 2])
 def test_one_million_hashes_threshold_32(eng, oracle, kernel):
     """BASELINE config 3: 1M synthetic hashes, 1000 injected 5-member clusters + the distance-32 pair.
     The expected edge set follows from the construction (random 256-bit pairs at d <= 32 have
