@@ -122,18 +122,21 @@ __device__ __forceinline__ Row8 pack_row(const Px8 &v, bool zero)
     const h2 k_0r = h2{(_Float16)0.0f, (_Float16)299.0f};      // (prev b, r)
     const h2 k_gb = h2{(_Float16)587.0f, (_Float16)114.0f};    // (g, b)
     const float bias = 500.0f - 1024.0f * 1000.0f;
-    float l[8];
+    // luma = floor(n / 1000) without a trunc: y = fma(n, 0.001f, 1024) lies in [1024, 1280), where consecutive f16 numbers are
+    // 1 apart, so the round-toward-zero f16 conversion IS the floor (fl(0.001f) > 0.001 and the fused rounding error is
+    // < 7e-5, far below the 0.001 spacing of the fractional parts); the 1024 bias leaves exactly in f16.
+    h2 packed[4];
 #pragma unroll
     for (int pp = 0; pp < 4; pp++) {  // two pixels = 6 bytes = pairs 3pp, 3pp+1, 3pp+2
         const float n0 = __builtin_amdgcn_fdot2(P[3 * pp], k_rg, __builtin_amdgcn_fdot2(P[3 * pp + 1], k_b0, bias, false), false);
         const float n1 = __builtin_amdgcn_fdot2(P[3 * pp + 1], k_0r, __builtin_amdgcn_fdot2(P[3 * pp + 2], k_gb, bias, false), false);
-        l[2 * pp] = __builtin_truncf(n0 * 0.001f);
-        l[2 * pp + 1] = __builtin_truncf(n1 * 0.001f);
+        const float y0 = __builtin_fmaf(n0, 0.001f, 1024.0f), y1 = __builtin_fmaf(n1, 0.001f, 1024.0f);
+        packed[pp] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(y0, y1)) - h2{(_Float16)1024.0f, (_Float16)1024.0f};
     }
     Row8 r;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        r.q[i] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(l[2 * i], l[2 * i + 1]));
+        r.q[i] = packed[i];
         if (zero) r.q[i] = h2{(_Float16)0, (_Float16)0};
     }
     return r;

@@ -137,6 +137,16 @@ def test_luma_float_formula_equals_integer_division():
     assert np.array_equal(got, num // 1000)
 
 
+def test_luma_fma_bias_then_rtz_f16_is_floor():
+    """kernel luma (current form): y = fma(n, 0.001f, 1024.0f) lies in [1024, 1280) where f16 numbers are 1 apart, so the
+    round-toward-zero f32 -> f16 conversion (v_cvt_pkrtz_f16_f32) is floor(n / 1000) + 1024 for every reachable numerator."""
+    num = np.arange(500, 255 * 1000 + 501, dtype=np.int64)
+    c = np.float64(f32(0.001))
+    y = (num.astype(np.float64) * c + 1024.0).astype(f32)          # product and sum exact in f64 -> one rounding = fma
+    assert np.array_equal(np.floor(y.astype(np.float64)).astype(np.int64), num // 1000 + 1024)
+    assert y.min() >= 1024 and y.max() < 1280                      # inside the binade where f16 spacing is exactly 1
+
+
 def test_markstein_division_is_ieee_for_all_numerators():
     """(6): every numerator the kernel divides is an integer multiple of 8 below 2^22; divisors 5, 6, 7 (and 8, 4 exact)."""
     N = (np.arange(0, 16320 * 4 + 1, dtype=np.int64) * 8).astype(f32)
