@@ -95,6 +95,16 @@ int rph_pdq_hash_batch_dev(rph_ctx *ctx, const void *d_px, uint32_t n, uint32_t 
                            void *d_hash32, void *d_quality, void *d_coeffs, void *d_dihedral,
                            void *d_valid, void *stream);
 
+/*
+ * generate_pdq_features for ONE image, as scanner.rs:1410 calls it from many rayon workers at once: thread-safe and
+ * blocking; concurrent callers with the same geometry are coalesced into one GPU batch (the first caller of a batch
+ * waits at most `max_wait_us` for others, default 256 images / 1000 us).  Same outputs as rph_pdq_hash_batch with n = 1.
+ */
+int rph_pdq_hash_one(rph_ctx *ctx, const uint8_t *px, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride,
+                     uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *valid_out);
+int rph_pdq_batcher_config(rph_ctx *ctx, uint32_t max_batch, uint32_t max_wait_us);
+int rph_pdq_batcher_stats(rph_ctx *ctx, uint64_t *n_batches_out, uint64_t *n_images_out);
+
 /* PdqFeatures::to_hash (pdqhash.rs:59-61) and generate_dihedral_hashes (:71-87)
  * for n stored coefficient vectors (n x 256 floats), e.g. features read back
  * from the cache (scanner.rs:1270-1272).  hash32_out / dihedral_out nullable. */

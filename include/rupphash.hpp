@@ -74,15 +74,16 @@ struct PdqFeatures {                      // pdqhash.rs:48-51
     }
 };
 
-// pdqhash.rs:166-196.  nullopt <=> None (width or height < 5).
+// pdqhash.rs:166-196.  nullopt <=> None (width or height < 5).  Thread-safe like the original: the scanner calls it from
+// every rayon worker (scanner.rs:1410); concurrent calls share one GPU batch inside the library (rph_pdq_hash_one).
 inline std::optional<std::pair<PdqFeatures, float>> generate_pdq_features(const ImageView &img)
 {
     PdqFeatures f{};
     Hash h{};
     float q = 0.f;
     uint8_t valid = 0;
-    check(rph_pdq_hash_batch(Context::get(), img.data, 1, img.width, img.height, img.channels, (size_t)img.width * img.channels,
-                             (size_t)img.width * img.height * img.channels, h.data(), &q, f.coefficients.data(), nullptr, &valid),
+    check(rph_pdq_hash_one(Context::get(), img.data, img.width, img.height, img.channels, (size_t)img.width * img.channels, h.data(), &q,
+                           f.coefficients.data(), &valid),
           "generate_pdq_features");
     if (!valid) return std::nullopt;
     return std::make_pair(f, q);

@@ -49,6 +49,9 @@ SIGNATURES = {
                                      _f32p, _u8p, _u8p]),
     "rph_pdq_hash_batch_dev": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _sz, _sz, _vp, _vp, _vp,
                                          _vp, _vp, _vp]),
+    "rph_pdq_hash_one": (C.c_int, [_vp, _u8p, C.c_uint32, C.c_uint32, C.c_uint32, _sz, _u8p, _f32p, _f32p, _u8p]),
+    "rph_pdq_batcher_config": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "rph_pdq_batcher_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rph_pdq_hashes_from_coeffs": (C.c_int, [_vp, _f32p, C.c_uint32, _u8p, _u8p]),
     "rph_pdq_hashes_from_coeffs_dev": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp]),
     "rph_pdq_set_kernel": (C.c_int, [_vp, C.c_int]),

@@ -169,6 +169,7 @@ int rph_init(int device, rph_ctx **out)
 int rph_shutdown(rph_ctx *ctx)
 {
     if (!ctx) return RPH_ERR_INVALID_ARG;
+    rph_batcher_forget(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);

@@ -55,6 +55,9 @@ int rph_launch_synth_images(uint8_t *d_out, uint64_t first_k, uint32_t n, uint32
 int rph_launch_synth_hashes(uint8_t *d_out, uint64_t first, uint64_t count, uint64_t n_total, uint64_t seed,
                             uint64_t n_clusters, hipStream_t stream);
 
+// batcher.cpp
+void rph_batcher_forget(rph_ctx *ctx);
+
 // host_grouping.cpp
 int rph_host_union_find(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,
                         uint32_t *n_groups_out);

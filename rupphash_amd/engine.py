@@ -79,6 +79,33 @@ class Engine:
               "rph_pdq_hash_batch")
         return out
 
+    def pdq_hash_one(self, image, want_coeffs=True):
+        """One image through the batching queue (thread-safe; concurrent callers share a GPU batch).
+        Returns (hash, quality, coeffs or None) or None when the image is too small (pdqhash.rs:167-169)."""
+        image = np.ascontiguousarray(image, np.uint8)
+        if image.ndim == 2:
+            h, w = image.shape
+            ch = 1
+        else:
+            h, w, ch = image.shape
+        hash32 = np.zeros(32, np.uint8)
+        q = C.c_float()
+        coeffs = np.zeros(256, np.float32) if want_coeffs else None
+        valid = C.c_uint8()
+        check(self.L.rph_pdq_hash_one(self.ctx, _ptr(image), w, h, ch, w * ch, _ptr(hash32), C.cast(C.byref(q), C.c_void_p), _ptr(coeffs),
+                                      C.cast(C.byref(valid), C.c_void_p)), "rph_pdq_hash_one")
+        if not valid.value:
+            return None
+        return hash32, q.value, coeffs
+
+    def pdq_batcher_config(self, max_batch=256, max_wait_us=1000):
+        check(self.L.rph_pdq_batcher_config(self.ctx, max_batch, max_wait_us), "rph_pdq_batcher_config")
+
+    def pdq_batcher_stats(self):
+        nb, ni = C.c_uint64(), C.c_uint64()
+        check(self.L.rph_pdq_batcher_stats(self.ctx, C.byref(nb), C.byref(ni)), "rph_pdq_batcher_stats")
+        return nb.value, ni.value
+
     def pdq_hash_batch_dev(self, d_px, n, w, h, channels, d_hash, d_quality=None, d_coeffs=None, d_dihedral=None,
                            d_valid=None, row_stride=None, image_stride=None, stream=None):
         row_stride = w * channels if row_stride is None else row_stride

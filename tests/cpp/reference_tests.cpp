@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <random>
 
+#include <thread>
+
 #include "rupphash.hpp"
 
 using namespace rupphash;
@@ -148,6 +150,25 @@ static void quality_and_dimensions()  // pdqhash.rs:631-647, :167-169
     EXPECT(!pdqhash::generate_pdq({flat.data(), 4, 64, 1}).has_value(), "4 px wide -> None");
     EXPECT(pdqhash::generate_pdq({flat.data(), 5, 5, 1}).has_value(), "5x5 -> Some");
 }
+static void generate_pdq_features_from_many_threads()  // scanner.rs:1202-1205, :1410: one call per file from every worker
+{
+    constexpr int T = 24, PER = 8, N = 96;
+    std::vector<std::vector<uint8_t>> imgs(T * PER, std::vector<uint8_t>((size_t)N * N * 3));
+    uint32_t s = 99;
+    for (auto &im : imgs)
+        for (auto &p : im) p = (uint8_t)((s = s * 1664525u + 1013904223u) >> 24);
+    std::vector<Hash> serial(imgs.size()), par(imgs.size());
+    for (size_t k = 0; k < imgs.size(); k++) serial[k] = pdqhash::generate_pdq({imgs[k].data(), N, N, 3})->first;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            for (int k = 0; k < PER; k++) par[t * PER + k] = pdqhash::generate_pdq({imgs[t * PER + k].data(), N, N, 3})->first;
+        });
+    for (auto &x : th) x.join();
+    EXPECT(serial == par, "hashes from concurrent callers equal the serial ones");
+    EXPECT(serial[0] != serial[1], "distinct images, distinct hashes");
+}
+
 static void test_high_similarity_support()  // hamminghash.rs:283-332
 {
     EXPECT(hamminghash::HammingHash<uint64_t>::hamming_distance(0, 0xFFF) == 12, "u64 distance");
@@ -227,6 +248,7 @@ int main()
     dihedral_set_is_the_full_group();
     dihedral_hashes_match_physically_transformed_buffer();
     quality_and_dimensions();
+    generate_pdq_features_from_many_threads();
     test_high_similarity_support();
     test_injected_cluster();
     phash_known_answer();

@@ -12,7 +12,7 @@ def build_cpp_tests():
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "reference_tests.cpp"), "-o", BIN,
                            "-L", os.path.join(ROOT, "rupphash_amd"), "-lrupphash_hip",
-                           "-Wl,-rpath," + os.path.join(ROOT, "rupphash_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+                           "-Wl,-rpath," + os.path.join(ROOT, "rupphash_amd"), "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
 
 
 def test_cpp_mirror_compiles():

@@ -510,3 +510,58 @@ def test_u64_find_groups_and_edges_match_oracle(eng, oracle, thr):
     brute = sorted((int(i), int(j), int(pc[i, j])) for i, j in zip(ii, jj))
     assert edge_set(edges) == brute
     assert eng.find_groups64(hashes, thr) == oracle.find_groups(oracle.KIND_U64, hashes, thr)
+
+
+# ---- batching queue (rph_pdq_hash_one): many threads, one image per call, as scanner.rs:1410 does
+def _hash_one_worker(eng, images, out, idx):
+    for k in idx:
+        out[k] = eng.pdq_hash_one(images[k])
+
+
+def test_hash_one_threads_coalesce_and_match_oracle(eng, oracle):
+    import threading
+    rng = np.random.default_rng(77)
+    images = [oracle.synth_images(4242 + k, 1)[0] for k in range(96)]                 # 512x512x3
+    images += [rng.integers(0, 256, (300, 200, 3), dtype=np.uint8) for _ in range(24)]  # generic geometry, own batches
+    images += [rng.integers(0, 256, (40, 4), dtype=np.uint8) for _ in range(4)]         # width 4 < 5 -> None (pdqhash.rs:167-169)
+    order = rng.permutation(len(images))
+    out = [None] * len(images)
+    eng.pdq_batcher_config(max_batch=32, max_wait_us=20000)
+    b0, i0 = eng.pdq_batcher_stats()
+    nthreads = 12
+    threads = [threading.Thread(target=_hash_one_worker, args=(eng, images, out, order[t::nthreads])) for t in range(nthreads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    b1, i1 = eng.pdq_batcher_stats()
+    assert i1 - i0 == len(images)
+    assert b1 - b0 < len(images) // 2, "concurrent callers were not coalesced"
+    for k, img in enumerate(images):
+        if img.ndim == 2:
+            assert out[k] is None
+            continue
+        rc, coeffs, q = oracle.pdq_features(img)
+        assert rc == 0
+        h, gq, gc = out[k]
+        assert np.array_equal(gc.view(np.uint32), coeffs.view(np.uint32)), k
+        assert np.float32(gq).view(np.uint32) == np.float32(q).view(np.uint32)
+        assert np.array_equal(h, oracle.to_hash(coeffs))
+    eng.pdq_batcher_config()
+
+
+def test_hash_one_single_caller_and_bad_args(eng, oracle):
+    img = oracle.synth_images(5, 1)[0]
+    eng.pdq_batcher_config(max_batch=256, max_wait_us=100)
+    h, q, c = eng.pdq_hash_one(img)
+    rc, coeffs, oq = oracle.pdq_features(img)
+    assert np.array_equal(c.view(np.uint32), coeffs.view(np.uint32))
+    h2, _, none = eng.pdq_hash_one(img, want_coeffs=False)
+    assert none is None and np.array_equal(h, h2)
+    from rupphash_amd import _lib
+    hash32 = np.zeros(32, np.uint8)
+    assert eng.L.rph_pdq_hash_one(eng.ctx, None, 512, 512, 3, 1536, hash32.ctypes.data, None, None, None) == _lib.RPH_ERR_INVALID_ARG
+    assert eng.L.rph_pdq_hash_one(eng.ctx, img.ctypes.data, 512, 512, 2, 1536, hash32.ctypes.data, None, None, None) == _lib.RPH_ERR_INVALID_ARG
+    assert eng.L.rph_pdq_hash_one(eng.ctx, img.ctypes.data, 512, 512, 3, 100, hash32.ctypes.data, None, None, None) == _lib.RPH_ERR_INVALID_ARG
+    assert eng.L.rph_pdq_batcher_config(eng.ctx, 0, 10) == _lib.RPH_ERR_INVALID_ARG
+    eng.pdq_batcher_config()
