@@ -38,6 +38,8 @@ namespace {
 constexpr int T_FILES = 1024;   // files per tile (rows and columns)
 constexpr int BLOCK = 128;      // threads per workgroup
 constexpr int R = T_FILES / BLOCK;  // row hashes per lane = 8
+// HIP requires gridDim.x * blockDim.x < 2^32 (a larger grid is silently truncated modulo 2^32): 2^22 blocks x <= 1024 threads
+constexpr unsigned long long MAX_GRID = 1ull << 22;
 
 struct SweepArgs {
     const uint32_t *rows;      // [n][n_variants][8] dwords (n_variants == 1: may alias cols)
@@ -50,6 +52,7 @@ struct SweepArgs {
     uint32_t mih_tol;          // find_groups chunk tolerance: 1 if threshold/16 >= 1 else 0
     uint32_t part, nparts;
     unsigned long long n_tile_pairs;
+    unsigned long long block0;  // first tile-pair slot of this launch (a launch carries at most MAX_GRID blocks)
     uint32_t n_tiles;
     rph_edge *edges;
     unsigned long long cap;
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(BLOCK) hamming_sweep_kernel(SweepArgs a)
 {
     __shared__ uint4 s_cols[T_FILES * 2];  // [column][2 x uint4] = 32 KiB
 
-    const unsigned long long p = (unsigned long long)a.part + (unsigned long long)blockIdx.x * a.nparts;
+    const unsigned long long p = (unsigned long long)a.part + (a.block0 + blockIdx.x) * a.nparts;
     if (p >= a.n_tile_pairs) return;
     uint32_t I, J;
     tile_pair(p, a.n_tiles, I, J);
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
     __shared__ uint32_t s_q[4][QCAP];   // one queue per wave: filled and drained by the same wave, no barrier needed
     __shared__ uint32_t s_qn[4];
 
-    const unsigned long long p = (unsigned long long)a.part + (unsigned long long)blockIdx.x * a.nparts;
+    const unsigned long long p = (unsigned long long)a.part + (a.block0 + blockIdx.x) * a.nparts;
     if (p >= a.n_tile_pairs) return;
     uint32_t I, J;
     tile_pair(p, a.n_tiles, I, J);
@@ -385,7 +388,7 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_fp4_kernel(SweepArgs a)
     __shared__ uint32_t s_q[4][QCAP];   // one queue per wave: filled and drained by the same wave, no barrier needed
     __shared__ uint32_t s_qn[4];
 
-    const unsigned long long p = (unsigned long long)a.part + (unsigned long long)blockIdx.x * a.nparts;
+    const unsigned long long p = (unsigned long long)a.part + (a.block0 + blockIdx.x) * a.nparts;
     if (p >= a.n_tile_pairs) return;
     uint32_t I, J;
     tile_pair(p, a.n_tiles, I, J);
@@ -544,7 +547,7 @@ struct Sweep64Args {
     const uint2 *hashes;  // [n] little-endian u64 as (lo, hi)
     unsigned long long n;
     uint32_t threshold, mih_tol, part, nparts, n_tiles;
-    unsigned long long n_tile_pairs;
+    unsigned long long n_tile_pairs, block0;
     rph_edge *edges;
     unsigned long long cap;
     unsigned long long *count;
@@ -553,7 +556,7 @@ struct Sweep64Args {
 __global__ void __launch_bounds__(256) hamming64_sweep_kernel(Sweep64Args a)
 {
     __shared__ uint2 s_cols[T_FILES];  // 8 KiB
-    const unsigned long long p = (unsigned long long)a.part + (unsigned long long)blockIdx.x * a.nparts;
+    const unsigned long long p = (unsigned long long)a.part + (a.block0 + blockIdx.x) * a.nparts;
     if (p >= a.n_tile_pairs) return;
     uint32_t I, J;
     tile_pair(p, a.n_tiles, I, J);
@@ -636,53 +639,46 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
     a.count = d_count;
     const unsigned long long mine = (a.n_tile_pairs > part) ? (a.n_tile_pairs - part + nparts - 1) / nparts : 0;
     if (mine == 0) return RPH_OK;
-    if (mine > 0x7FFFFFFFull) {
-        rph_set_error("hamming sweep: too many tile pairs for one launch (%llu)", mine);
-        return RPH_ERR_INVALID_ARG;
-    }
     // Partial-width test: unrelated 256-bit hashes differ in ~16*PW +- sqrt(8*PW) of the first
     // 32*PW bits; keep ~5 sigma between that and the threshold.
-    const dim3 grid((unsigned)mine), block(BLOCK);
-    if (use_mfma == 2) {
-        const dim3 mblock(MF_BLOCK);
-        if (a.threshold <= 36)
-            hipLaunchKernelGGL(hamming_fp4_kernel<4>, grid, mblock, 0, stream, a);
-        else if (a.threshold <= 60)
-            hipLaunchKernelGGL(hamming_fp4_kernel<6>, grid, mblock, 0, stream, a);
-        else
-            hipLaunchKernelGGL(hamming_fp4_kernel<8>, grid, mblock, 0, stream, a);
+    const uint32_t t = a.threshold;
+    for (unsigned long long b0 = 0; b0 < mine; b0 += MAX_GRID) {  // one launch carries at most MAX_GRID tile pairs
+        a.block0 = b0;
+        const dim3 grid((unsigned)((mine - b0) < MAX_GRID ? (mine - b0) : MAX_GRID)), block(BLOCK), mblock(MF_BLOCK);
+        if (use_mfma == 2) {
+            if (t <= 36)
+                hipLaunchKernelGGL(hamming_fp4_kernel<4>, grid, mblock, 0, stream, a);
+            else if (t <= 60)
+                hipLaunchKernelGGL(hamming_fp4_kernel<6>, grid, mblock, 0, stream, a);
+            else
+                hipLaunchKernelGGL(hamming_fp4_kernel<8>, grid, mblock, 0, stream, a);
+        } else if (use_mfma) {
+            if (t <= 36)
+                hipLaunchKernelGGL(hamming_mfma_kernel<4>, grid, mblock, 0, stream, a);
+            else if (t <= 48)
+                hipLaunchKernelGGL(hamming_mfma_kernel<5>, grid, mblock, 0, stream, a);
+            else if (t <= 60)
+                hipLaunchKernelGGL(hamming_mfma_kernel<6>, grid, mblock, 0, stream, a);
+            else if (t <= 74)
+                hipLaunchKernelGGL(hamming_mfma_kernel<7>, grid, mblock, 0, stream, a);
+            else
+                hipLaunchKernelGGL(hamming_mfma_kernel<8>, grid, mblock, 0, stream, a);
+        } else {
+            if (t <= 36)
+                hipLaunchKernelGGL(hamming_sweep_kernel<4>, grid, block, 0, stream, a);
+            else if (t <= 48)
+                hipLaunchKernelGGL(hamming_sweep_kernel<5>, grid, block, 0, stream, a);
+            else if (t <= 60)
+                hipLaunchKernelGGL(hamming_sweep_kernel<6>, grid, block, 0, stream, a);
+            else if (t <= 74)
+                hipLaunchKernelGGL(hamming_sweep_kernel<7>, grid, block, 0, stream, a);
+            else
+                hipLaunchKernelGGL(hamming_sweep_kernel<8>, grid, block, 0, stream, a);
+        }
         RPH_HIP_CHECK(hipGetLastError());
-        return RPH_OK;
     }
-    if (use_mfma) {
-        const dim3 mblock(MF_BLOCK);
-        if (a.threshold <= 36)
-            hipLaunchKernelGGL(hamming_mfma_kernel<4>, grid, mblock, 0, stream, a);
-        else if (a.threshold <= 48)
-            hipLaunchKernelGGL(hamming_mfma_kernel<5>, grid, mblock, 0, stream, a);
-        else if (a.threshold <= 60)
-            hipLaunchKernelGGL(hamming_mfma_kernel<6>, grid, mblock, 0, stream, a);
-        else if (a.threshold <= 74)
-            hipLaunchKernelGGL(hamming_mfma_kernel<7>, grid, mblock, 0, stream, a);
-        else
-            hipLaunchKernelGGL(hamming_mfma_kernel<8>, grid, mblock, 0, stream, a);
-        RPH_HIP_CHECK(hipGetLastError());
-        return RPH_OK;
-    }
-    if (a.threshold <= 36)
-        hipLaunchKernelGGL(hamming_sweep_kernel<4>, grid, block, 0, stream, a);
-    else if (a.threshold <= 48)
-        hipLaunchKernelGGL(hamming_sweep_kernel<5>, grid, block, 0, stream, a);
-    else if (a.threshold <= 60)
-        hipLaunchKernelGGL(hamming_sweep_kernel<6>, grid, block, 0, stream, a);
-    else if (a.threshold <= 74)
-        hipLaunchKernelGGL(hamming_sweep_kernel<7>, grid, block, 0, stream, a);
-    else
-        hipLaunchKernelGGL(hamming_sweep_kernel<8>, grid, block, 0, stream, a);
-    RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }
-
 
 int rph_launch_hamming64_sweep(const uint64_t *d_hashes, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts,
                                rph_edge *d_edges, uint64_t cap, unsigned long long *d_count, hipStream_t stream)
@@ -706,7 +702,10 @@ int rph_launch_hamming64_sweep(const uint64_t *d_hashes, uint64_t n, uint32_t th
     a.count = d_count;
     const unsigned long long mine = (a.n_tile_pairs > part) ? (a.n_tile_pairs - part + nparts - 1) / nparts : 0;
     if (mine == 0) return RPH_OK;
-    hipLaunchKernelGGL(hamming64_sweep_kernel, dim3((unsigned)mine), dim3(256), 0, stream, a);
-    RPH_HIP_CHECK(hipGetLastError());
+    for (unsigned long long b0 = 0; b0 < mine; b0 += MAX_GRID) {
+        a.block0 = b0;
+        hipLaunchKernelGGL(hamming64_sweep_kernel, dim3((unsigned)((mine - b0) < MAX_GRID ? (mine - b0) : MAX_GRID)), dim3(256), 0, stream, a);
+        RPH_HIP_CHECK(hipGetLastError());
+    }
     return RPH_OK;
 }

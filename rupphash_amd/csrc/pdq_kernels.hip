@@ -131,8 +131,14 @@ __global__ void __launch_bounds__(64) from_coeffs_kernel(const float *__restrict
 int rph_launch_pdq_from_coeffs(const float *d_coeffs, uint32_t n, uint8_t *d_hash, uint8_t *d_dihedral, hipStream_t stream)
 {
     if (n == 0) return RPH_OK;
-    hipLaunchKernelGGL(from_coeffs_kernel, dim3(n), dim3(64), 0, stream, d_coeffs, n, d_hash, d_dihedral);
-    RPH_HIP_CHECK(hipGetLastError());
+    constexpr uint32_t CHUNK = 1u << 24;  // gridDim.x * 64 threads must stay below 2^32
+    for (uint32_t first = 0; first < n; first += CHUNK) {
+        const uint32_t m = (n - first) < CHUNK ? (n - first) : CHUNK;
+        hipLaunchKernelGGL(from_coeffs_kernel, dim3(m), dim3(64), 0, stream, d_coeffs + (size_t)first * 256, m,
+                           d_hash ? d_hash + (size_t)first * 32 : nullptr, d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr);
+        RPH_HIP_CHECK(hipGetLastError());
+        if (n - first <= CHUNK) break;
+    }
     return RPH_OK;
 }
 

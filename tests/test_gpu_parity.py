@@ -333,12 +333,13 @@ def test_mih_build_matches_reference_csr(eng, oracle):
 
 
 # ------------------------------------------------------------------ full-size, construction-known answers
-@pytest.mark.parametrize("kernel", [1, 0, 2])
-def test_one_million_hashes_threshold_32(eng, oracle, kernel):
+@pytest.mark.parametrize("kernel,n", [(1, 1_000_000), (0, 1_000_000), (2, 1_000_000), (1, 3_100_000)])
+def test_one_million_hashes_threshold_32(eng, oracle, kernel, n):
     """BASELINE config 3: 1M synthetic hashes, 1000 injected 5-member clusters + the distance-32 pair.
     The expected edge set follows from the construction (random 256-bit pairs at d <= 32 have
-    probability ~1e-33), so the full-size sweep is checked exactly."""
-    n, nc = 1_000_000, 1000
+    probability ~1e-33), so the full-size sweep is checked exactly.  3.1M hashes = 4.6M tile pairs: more than one
+    launch can carry (gridDim.x * blockDim.x < 2^32), so the sweep is split across launches."""
+    nc = 1000
     d_h = eng.dev_alloc(n * 32)
     cap = 1 << 16
     d_e = eng.dev_alloc(cap * 12)
