@@ -108,31 +108,55 @@ __device__ __forceinline__ h2 h2_bits(uint32_t u) { return __builtin_bit_cast(h2
 __device__ __forceinline__ h2 byte_pair_lo(uint32_t d) { return h2_bits(__builtin_amdgcn_perm(0x64646464u, d, 0x04010400u)); }
 __device__ __forceinline__ h2 byte_pair_hi(uint32_t d) { return h2_bits(__builtin_amdgcn_perm(0x64646464u, d, 0x04030402u)); }
 
-__device__ __forceinline__ Row8 pack_row(const Px8 &v, bool zero)
+// a.x * k.x + a.y * k.y with f32 accumulation from the inline constant 0: the three-operand VOP3P form (the compiler would
+// otherwise emit v_mov 0 + the two-address v_dot2c)
+// `after` is not read by the instruction: it only orders this row behind the previous one, so that the scheduler cannot
+// hoist the dot products of all eight prefetched rows to the top of the loop (64 live values, spills).
+__device__ __forceinline__ float dot2_from_zero(h2 a, h2 k, uint32_t after)
 {
-    // byte stream r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3 | ... : pair p holds bytes 2p, 2p+1
-    h2 P[12];
+    float r;
+    asm volatile("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, a)), "s"(__builtin_bit_cast(uint32_t, k)), "v"(after));
+    return r;
+}
+
+struct Pairs12 {
+    h2 P[12];  // byte stream r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3 | ... : pair p holds bytes 2p, 2p+1 as f16 1024 + byte
+};
+__device__ __forceinline__ Pairs12 byte_pairs(const Px8 &v)
+{
+    Pairs12 r;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        P[2 * i] = byte_pair_lo(v.d[i]);
-        P[2 * i + 1] = byte_pair_hi(v.d[i]);
+        r.P[2 * i] = byte_pair_lo(v.d[i]);
+        r.P[2 * i + 1] = byte_pair_hi(v.d[i]);
     }
+    return r;
+}
+__device__ __forceinline__ Row8 luma_row(const Pairs12 &pr, bool zero, uint32_t &order)
+{
+    const h2 *P = pr.P;
     const h2 k_rg = h2{(_Float16)299.0f, (_Float16)587.0f};   // (r, g)
     const h2 k_b0 = h2{(_Float16)114.0f, (_Float16)0.0f};      // (b, next r)
     const h2 k_0r = h2{(_Float16)0.0f, (_Float16)299.0f};      // (prev b, r)
     const h2 k_gb = h2{(_Float16)587.0f, (_Float16)114.0f};    // (g, b)
-    const float bias = 500.0f - 1024.0f * 1000.0f;
-    // luma = floor(n / 1000) without a trunc: y = fma(n, 0.001f, 1024) lies in [1024, 1280), where consecutive f16 numbers are
-    // 1 apart, so the round-toward-zero f16 conversion IS the floor (fl(0.001f) > 0.001 and the fused rounding error is
-    // < 7e-5, far below the 0.001 spacing of the fractional parts); the 1024 bias leaves exactly in f16.
+    // The 1024 bias of every byte adds 1024 * (299 + 587 + 114) = 1024 * 1000 to the numerator: n = 1 024 000 + (299 r + 587 g + 114 b)
+    // (< 2^24, exact), so y = fma(n, 0.001f, 0.5f) = 1024 + (299 r + 587 g + 114 b + 500) / 1000 lies in [1024.5, 1280), where
+    // consecutive f16 numbers are 1 apart: the round-toward-zero f16 conversion IS the floor (fl(0.001f) > 0.001 and the fused
+    // rounding error is < 1.3e-4, far below the 0.001 spacing of the fractional parts), and the accumulators start from the
+    // inline constant 0 (no v_mov of a bias).
+    // 0.5 kept in a VGPR the compiler cannot see through: with an inline-constant addend it would pick the VOP3 v_fma_f32, which
+    // issues at half the rate of the VOP2 v_fmamk_f32 (tools/valu_rate.hip)
+    float vhalf;
+    asm("v_mov_b32 %0, 0.5" : "=v"(vhalf));
     h2 packed[4];
 #pragma unroll
     for (int pp = 0; pp < 4; pp++) {  // two pixels = 6 bytes = pairs 3pp, 3pp+1, 3pp+2
-        const float n0 = __builtin_amdgcn_fdot2(P[3 * pp], k_rg, __builtin_amdgcn_fdot2(P[3 * pp + 1], k_b0, bias, false), false);
-        const float n1 = __builtin_amdgcn_fdot2(P[3 * pp + 1], k_0r, __builtin_amdgcn_fdot2(P[3 * pp + 2], k_gb, bias, false), false);
-        const float y0 = __builtin_fmaf(n0, 0.001f, 1024.0f), y1 = __builtin_fmaf(n1, 0.001f, 1024.0f);
+        const float n0 = __builtin_amdgcn_fdot2(P[3 * pp], k_rg, dot2_from_zero(P[3 * pp + 1], k_b0, order), false);
+        const float n1 = __builtin_amdgcn_fdot2(P[3 * pp + 1], k_0r, dot2_from_zero(P[3 * pp + 2], k_gb, order), false);
+        const float y0 = __builtin_fmaf(n0, 0.001f, vhalf), y1 = __builtin_fmaf(n1, 0.001f, vhalf);  // v_fmamk_f32 (VOP2, full rate)
         packed[pp] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(y0, y1)) - h2{(_Float16)1024.0f, (_Float16)1024.0f};
     }
+    order = __builtin_bit_cast(uint32_t, packed[3]);
     Row8 r;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -141,6 +165,7 @@ __device__ __forceinline__ Row8 pack_row(const Px8 &v, bool zero)
     }
     return r;
 }
+__device__ __forceinline__ Row8 pack_row(const Px8 &v, bool zero, uint32_t &order) { return luma_row(byte_pairs(v), zero, order); }
 __device__ __forceinline__ uint4 row_bits(const Row8 &r)
 {
     uint4 u;
@@ -182,6 +207,7 @@ struct Wave {
     uint8_t *lds;
     const uint8_t *img;
     size_t row_stride;
+    uint32_t rs32;  // row_stride (the launcher guarantees 512 * row_stride < 2^32)
     int lane;
     // scan state (lane = row of the band), carried across the 8 strips of a band
     float hs, sum, ring[8];
@@ -205,26 +231,50 @@ struct Wave {
 template <class G>
 __device__ __forceinline__ int half_row(int b, int h, int g, int k) { return 64 * b + 4 + (G::NG * 8) * h + 8 * g + k; }
 
-// LOAD phase 1: issue the 16 loads of half tile (b, s, h)
+// Byte offset (from the image base, < 2^32: the launcher checks 512 * row_stride) of the first of the 8 rows this lane loads in
+// half tile (b, s, h), and the largest offset it may use (row 511 of its columns: rows beyond the image are re-reads of row 511
+// and are zeroed in luma_row)
+template <class G>
+__device__ __forceinline__ void half_offsets(const Wave &w, int b, int s, int h, uint32_t &off0, uint32_t &off_max)
+{
+    const int c = w.lane & (G::CL - 1), g = w.lane / G::CL;
+    const uint32_t col = (uint32_t)(G::SW * s + 8 * c) * 3u;
+    off0 = (uint32_t)half_row<G>(b, h, g, 0) * w.rs32 + col;
+    off_max = 511u * w.rs32 + col;
+}
+__device__ __forceinline__ Px8 load_px8_at(const Wave &w, uint32_t off) { return load_px8(w.img + off); }  // uniform base + 32-bit lane offset
+
+// LOAD phase 1 (only for the very first tile of the image): issue the 16 loads of half tile (b, s, h)
 template <class G>
 __device__ __forceinline__ void half_issue(const Wave &w, int b, int s, int h, Px8 (&pre)[8])
 {
-    const int c = w.lane & (G::CL - 1), g = w.lane / G::CL;
+    uint32_t off, off_max;
+    half_offsets<G>(w, b, s, h, off, off_max);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        int y = half_row<G>(b, h, g, k);
-        y = y > 511 ? 511 : y;  // rows beyond the image are zeroed in half_luma
-        pre[k] = load_px8(w.img + (size_t)y * w.row_stride + (size_t)(G::SW * s + 8 * c) * 3);
+        pre[k] = load_px8_at(w, off);
+        off = off + w.rs32;
+        off = off < off_max ? off : off_max;
     }
 }
 
-// LOAD phase 2a: luma of the 8 prefetched rows (frees the prefetch registers for the next half tile's loads)
+// LOAD phase 2a: luma of the 8 prefetched rows of half tile (b, *, h); as soon as a row's bytes have been widened, its
+// registers are refilled with the same row of the next half tile (nb, ns, nh) -- the loads are spread over the luma phase
 template <class G, bool LAST_BAND>
-__device__ __forceinline__ void half_luma(const Wave &w, int b, int h, const Px8 (&pre)[8], Row8 (&L)[8])
+__device__ __forceinline__ void half_luma(const Wave &w, int b, int h, Px8 (&pre)[8], Row8 (&L)[8], bool has_next, int nb, int ns, int nh)
 {
     const int g = w.lane / G::CL;
+    uint32_t off, off_max;
+    half_offsets<G>(w, nb, ns, nh, off, off_max);
+    uint32_t order = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) L[k] = pack_row(pre[k], LAST_BAND && (half_row<G>(b, h, g, k) >= 512));
+    for (int k = 0; k < 8; k++) {
+        const Pairs12 pr = byte_pairs(pre[k]);
+        if (has_next) pre[k] = load_px8_at(w, off);
+        off = off + w.rs32;
+        off = off < off_max ? off : off_max;
+        L[k] = luma_row(pr, LAST_BAND && (half_row<G>(b, h, g, k) >= 512), order);
+    }
 }
 
 // LOAD phase 2b: exchange of the 7 rows above, vertical window sums, 32 rows of the V tile
@@ -535,14 +585,17 @@ __device__ __forceinline__ void do_band(Wave &w, int b, Px8 (&pre)[8])
 #pragma unroll 1
         for (int h = 0; h < G::NH; h++) {
             Row8 L[8];
-            half_luma<G, KIND == 2>(w, b, h, pre, L);
             // next build step in processing order: (b,s,1) -> (b,s+1,0) -> ... -> (b+1,0,0)
-            if (h + 1 < G::NH)
-                half_issue<G>(w, b, s, h + 1, pre);
-            else if (s < G::NSTRIP - 1)
-                half_issue<G>(w, b, s + 1, 0, pre);
-            else if (b < 7)
-                half_issue<G>(w, b + 1, 0, 0, pre);
+            int nb = b, ns = s, nh = h + 1;
+            if (nh == G::NH) {
+                nh = 0;
+                ns = s + 1;
+                if (ns == G::NSTRIP) {
+                    ns = 0;
+                    nb = b + 1;
+                }
+            }
+            half_luma<G, KIND == 2>(w, b, h, pre, L, nb < 8, nb, ns, nh);
             half_build<G>(w, s, h, L);
         }
         if (s == 0)
@@ -573,6 +626,7 @@ __global__ void __launch_bounds__(64, G::WAVES_PER_SIMD) pdq_fused512_kernel(con
     w.lds = lds;
     w.img = px + (size_t)img * image_stride;
     w.row_stride = row_stride;
+    w.rs32 = (uint32_t)row_stride;
     w.lane = threadIdx.x;
     w.csum = 0.f;
     w.smp_last = 0.f;
@@ -590,12 +644,13 @@ __global__ void __launch_bounds__(64, G::WAVES_PER_SIMD) pdq_fused512_kernel(con
         for (int j = 0; j < 3; j++)
             for (int t = w.lane; t < 64; t += 64) *reinterpret_cast<uint4 *>(lds + G::OFF_STATE + j * 1024 + t * 16) = make_uint4(0, 0, 0, 0);
         // rows 0..3 x 64 column chunks of 8 px = 256 (row, chunk) slots, 64 per iteration
+        uint32_t order = 0;
 #pragma unroll 1
         for (int it = 0; it < 4; it++) {
             const int slot = it * 64 + w.lane;
             const int chunk = slot & 63, row = slot >> 6;
             const Px8 p = load_px8(w.img + (size_t)row * row_stride + (size_t)(8 * chunk) * 3);
-            *reinterpret_cast<uint4 *>(lds + G::OFF_STATE + (3 + row) * 1024 + (8 * chunk) * 2) = row_bits(pack_row(p, false));
+            *reinterpret_cast<uint4 *>(lds + G::OFF_STATE + (3 + row) * 1024 + (8 * chunk) * 2) = row_bits(pack_row(p, false, order));
         }
     }
     edge_prologue<G>(w);

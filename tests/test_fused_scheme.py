@@ -138,12 +138,16 @@ def test_luma_float_formula_equals_integer_division():
 
 
 def test_luma_fma_bias_then_rtz_f16_is_floor():
-    """kernel luma (current form): y = fma(n, 0.001f, 1024.0f) lies in [1024, 1280) where f16 numbers are 1 apart, so the
-    round-toward-zero f32 -> f16 conversion (v_cvt_pkrtz_f16_f32) is floor(n / 1000) + 1024 for every reachable numerator."""
-    num = np.arange(500, 255 * 1000 + 501, dtype=np.int64)
+    """kernel luma (current form): every byte enters the dot products as the f16 number 1024 + v, so the accumulated numerator is
+    n = 1 024 000 + (299 r + 587 g + 114 b) (exact, < 2^24) and y = fma(n, 0.001f, 0.5f) = 1024 + (299r+587g+114b+500)/1000 lies in
+    [1024.5, 1280), where f16 numbers are 1 apart, so the round-toward-zero f32 -> f16 conversion (v_cvt_pkrtz_f16_f32) is
+    floor((299r+587g+114b+500) / 1000) + 1024 for every reachable numerator."""
+    x = np.arange(0, 255 * 1000 + 1, dtype=np.int64)               # 299 r + 587 g + 114 b
+    n = x + 1024 * 1000
+    assert n.max() < 2 ** 24
     c = np.float64(f32(0.001))
-    y = (num.astype(np.float64) * c + 1024.0).astype(f32)          # product and sum exact in f64 -> one rounding = fma
-    assert np.array_equal(np.floor(y.astype(np.float64)).astype(np.int64), num // 1000 + 1024)
+    y = (n.astype(np.float64) * c + 0.5).astype(f32)               # product and sum exact in f64 -> one rounding = fma
+    assert np.array_equal(np.floor(y.astype(np.float64)).astype(np.int64), (x + 500) // 1000 + 1024)
     assert y.min() >= 1024 and y.max() < 1280                      # inside the binade where f16 spacing is exactly 1
 
 

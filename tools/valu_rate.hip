@@ -36,6 +36,19 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed, unsigned 
                 if (OP == 10) asm volatile("v_trunc_f32 %0, %0" : "+v"(f[i]));
                 if (OP == 11) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %1" : "=v"(a[i]) : "v"(f[i]));
                 if (OP == 12) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fs));
+                if (OP == 13) asm volatile("v_dot2c_f32_f16 %0, 0x60965cac, %1" : "+v"(f[i]) : "v"(s));
+                if (OP == 14) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(s));
+                if (OP == 15) asm volatile("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(f[i]) : "v"(s), "s"(seed));
+                if (OP == 16) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(f[i]) : "v"(fs));
+                if (OP == 17) asm volatile("v_fmamk_f32 %0, %1, 0x3a83126f, %0" : "+v"(f[i]) : "v"(fs));
+                if (OP == 18) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fs));
+                if (OP == 19) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "v"(s));
+                if (OP == 20) asm volatile("v_dot2_f32_f16 %0, %1, %1, 0" : "=v"(f[i]) : "v"(s));
+                if (OP == 21) asm volatile("v_fma_f32 %0, %0, %1, 0.5" : "+v"(f[i]) : "s"(seed));
+                if (OP == 22) asm volatile("v_mov_b32 %0, 0" : "=v"(a[i]));
+                if (OP == 23) asm volatile("v_pk_add_f16 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(a[i]) : "s"(seed));
+                if (OP == 24) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(s));
+                if (OP == 25) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(s));
             }
         }
     }
@@ -95,7 +108,9 @@ int main()
     hipMalloc(&out, (size_t)blocks * threads * 4);
     hipMalloc(&clk, 16);
     const char *names[] = {"v_xor_b32", "v_bcnt_u32_b32", "v_fma_f32", "v_add_f32", "v_perm_b32", "v_dot2_f32_f16", "v_pk_add_f16",
-                           "v_fma_mix_f32", "v_cvt_f32_ubyte0", "v_min3_u32", "v_trunc_f32", "v_cvt_pkrtz_f16_f32", "v_mul_f32"};
+                           "v_fma_mix_f32", "v_cvt_f32_ubyte0", "v_min3_u32", "v_trunc_f32", "v_cvt_pkrtz_f16_f32", "v_mul_f32",
+                           "v_dot2c_f32_f16 literal", "v_mov_b32 v", "v_dot2_f32_f16 v,s,0", "v_fmac_f32", "v_fmamk_f32", "v_sub_f32", "v_add_u32",
+                           "v_dot2_f32_f16 v,v,0", "v_fma_f32 v,s,0.5", "v_mov_b32 0", "v_pk_add_f16 v,s", "v_lshl_add_u32", "v_cndmask_b32"};
     const double insts = (double)blocks * (threads / 64) * ITER * UNROLL;  // wave-instructions
     double ghz = 0;
 #define RUN(OP)                                                                                                      \
@@ -107,7 +122,7 @@ int main()
         double per_simd_clk = insts * 64 / (ms * 1e-3) / (ghz * 1e9) / 1024.0;                                       \
         std::printf("%-22s %8.3f ms  clock %.2f GHz  %6.2f lanes/clk/SIMD  (%.1f T lane-op/s)\n", names[OP], ms, ghz, per_simd_clk, insts * 64 / (ms * 1e-3) / 1e12); \
     }
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25)
     const char *pk[] = {"v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32"};
 #define RUNPK(OP)                                                                                                    \
     {                                                                                                                \
