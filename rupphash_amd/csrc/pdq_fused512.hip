@@ -479,7 +479,8 @@ __device__ __forceinline__ void col_pass(Wave &w, int b, bool second_half)
 //   (FIRST: also consumes the chain's phase 1 = luma rows 0..3)
 __device__ __forceinline__ void edge_rowvals(const Wave &w, int y, bool live, float (&rv)[6])
 {
-    // lane = luma row y: R = horizontal clipped window sum of luma (exact), rowval x 64 = (64 R) / window
+    // lane = luma row y: R = horizontal clipped window sum of luma (exact), rowval x 64 = (64 R) / window; the numerators are
+    // multiples of 64 below 2^17 and the divisors 5, 6, 7, so div_small gives the IEEE quotient
     const int yc = y > 511 ? 511 : y;
     const Px8 pl = load_px8(w.img + (size_t)yc * w.row_stride);
     const Px8 pr = load_px8(w.img + (size_t)yc * w.row_stride + 504 * 3);
@@ -492,12 +493,12 @@ __device__ __forceinline__ void edge_rowvals(const Wave &w, int y, bool live, fl
     const float q510 = (((r[3] + r[4]) + r[5]) + r[6]) + r[7];
     const float q509 = q510 + r[2];
     const float q508 = q509 + r[1];
-    rv[0] = (r0 * 64.0f) / 5.0f;
-    rv[1] = (r1 * 64.0f) / 6.0f;
-    rv[2] = (r2 * 64.0f) / 7.0f;
-    rv[3] = (q508 * 64.0f) / 7.0f;
-    rv[4] = (q509 * 64.0f) / 6.0f;
-    rv[5] = (q510 * 64.0f) / 5.0f;
+    rv[0] = div_small(r0 * 64.0f, 5.0f, 1.0f / 5.0f);
+    rv[1] = div_small(r1 * 64.0f, 6.0f, 1.0f / 6.0f);
+    rv[2] = div_small(r2 * 64.0f, 7.0f, 1.0f / 7.0f);
+    rv[3] = div_small(q508 * 64.0f, 7.0f, 1.0f / 7.0f);
+    rv[4] = div_small(q509 * 64.0f, 6.0f, 1.0f / 6.0f);
+    rv[5] = div_small(q510 * 64.0f, 5.0f, 1.0f / 5.0f);
     if (!live) {
 #pragma unroll
         for (int k = 0; k < 6; k++) rv[k] = 0.f;
