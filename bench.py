@@ -132,9 +132,34 @@ def main():
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
     value = world * n_img * args.steps / elapsed
     achieved_gbs = ALGO_BYTES_PER_IMAGE * n_img / (avg_kernel_ms * 1e-3) / 1e9
+    # what a pure read stream over the same resident images gets on this GPU (untimed part of the job; rank 0's figure is reported)
+    read_gbs = None
+    if rank == 0:
+        eng.read_stream_dev(imgs.data_ptr(), n_img * IMG_BYTES, stream=stream)
+        ra, rb = eng.event(), eng.event()
+        eng.event_record(ra, stream)
+        for _ in range(3):
+            eng.read_stream_dev(imgs.data_ptr(), n_img * IMG_BYTES, stream=stream)
+        eng.event_record(rb, stream)
+        torch.cuda.synchronize()
+        read_gbs = 3.0 * n_img * IMG_BYTES / (eng.event_elapsed_ms(ra, rb) * 1e-3) / 1e9
+        eng.event_destroy(ra)
+        eng.event_destroy(rb)
     hash_checksum = int(hashes.to(torch.int64).sum().item())
     pdq_sample = hashes[:64].cpu().numpy()
     img_sample = imgs[:64].cpu().numpy().reshape(64, 512, 512, 3)
+
+    # HBM traffic per launch: rocprofv3 cannot run inside this process, so the figure is the PMC measurement of this same kernel
+    # committed under profiles/ (FETCH_SIZE, corrected as MI355X_MICROARCH.md prescribes), scaled to this launch's image count
+    traffic_bytes, traffic_source = None, None
+    tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pdq_traffic.json")
+    if os.path.exists(tfile):
+        with open(tfile) as f:
+            tj = json.load(f)
+        per_image = tj.get({0: "generic", 1: "fused512_strip64", 2: "fused512_strip128"}[args.pdq_kernel])
+        if per_image:
+            traffic_bytes = per_image * n_img
+            traffic_source = tj.get("source")
 
     # ------------------------------------------------------------------ phase B: Hamming sweep
     del imgs
@@ -223,8 +248,12 @@ def main():
                    "images_per_gpu": n_img, "image": "512x512x3 u8", "pdq_kernel": {0: "generic", 1: "fused512/strip64", 2: "fused512/strip128"}[args.pdq_kernel],
                    "hash_checksum": hash_checksum},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "kernel_ms": avg_kernel_ms, "algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE},
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic_bytes,
+                     "traffic_source": traffic_source,
+                     "kernel_ms": avg_kernel_ms, "algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE,
+                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_IMAGE * n_img,
+                     "measured_read_stream_gbs": read_gbs,
+                     "frac_of_measured_read_stream": (achieved_gbs / read_gbs) if read_gbs else None},
         "hamming": {"metric": "hamming256_pair_comparisons_per_sec", "value": gpairs, "unit": "Gpairs/s",
                     "n_hashes": n_h, "threshold": args.threshold, "steps": h_steps, "ms_per_step": h_elapsed / h_steps * 1e3,
                     "scaling": "weak (pairs per GPU fixed: n = 1M*sqrt(N))", "edges_found": n_edges,

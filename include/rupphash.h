@@ -255,6 +255,11 @@ int rph_synth_images_dev(rph_ctx *ctx, void *d_out, uint64_t first_k, uint32_t n
 int rph_synth_hashes_dev(rph_ctx *ctx, void *d_out, uint64_t first, uint64_t count, uint64_t n_total,
                          uint64_t seed, uint64_t n_clusters, void *stream);
 
+/* Measurement aid for bench.py: one pure read pass over a resident device buffer (16-byte aligned), on `stream`.
+ * Timed with the event hooks below it gives the read bandwidth this GPU actually delivers to a streaming kernel --
+ * the practical ceiling of the PDQ kernel, which reads every image byte exactly once and writes 32 bytes. */
+int rph_read_stream_dev(rph_ctx *ctx, const void *d_buf, size_t bytes, void *stream);
+
 /* Device memory helpers for callers without a HIP binding (tests, bench). */
 int rph_dev_alloc(rph_ctx *ctx, size_t bytes, void **d_ptr_out);
 int rph_dev_free(rph_ctx *ctx, void *d_ptr);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "rph_phash_dihedral": (None, [C.c_uint64, _u64p]),
     "rph_synth_images_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "rph_synth_hashes_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
+    "rph_read_stream_dev": (C.c_int, [_vp, _vp, _sz, _vp]),
     "rph_dev_alloc": (C.c_int, [_vp, _sz, C.POINTER(C.c_void_p)]),
     "rph_dev_free": (C.c_int, [_vp, _vp]),
     "rph_dev_upload": (C.c_int, [_vp, _vp, _vp, _sz]),

@@ -173,6 +173,7 @@ int rph_shutdown(rph_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->sink) (void)hipFree(ctx->sink);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RPH_OK;
@@ -552,6 +553,15 @@ int rph_synth_hashes_dev(rph_ctx *ctx, void *d_out, uint64_t first, uint64_t cou
     if (!ctx || (!d_out && count)) return RPH_ERR_INVALID_ARG;
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
     return rph_launch_synth_hashes((uint8_t *)d_out, first, count, n_total, seed, n_clusters, pick(ctx, stream));
+}
+
+int rph_read_stream_dev(rph_ctx *ctx, const void *d_buf, size_t bytes, void *stream)
+{
+    if (!ctx || !d_buf || ((uintptr_t)d_buf % 16) != 0) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->sink) RPH_HIP_CHECK(hipMalloc((void **)&ctx->sink, 16));
+    return rph_launch_read_stream(d_buf, bytes, ctx->sink, pick(ctx, stream));
 }
 
 int rph_dev_alloc(rph_ctx *ctx, size_t bytes, void **out)

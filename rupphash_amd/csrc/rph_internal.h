@@ -14,6 +14,7 @@ struct rph_ctx {
     // scratch for the generic (multi-pass) PDQ kernel: two f32 planes per in-flight image
     float *scratch = nullptr;
     size_t scratch_bytes = 0;
+    uint32_t *sink = nullptr;  // 4-byte result slot of the read-stream probe
     int hamming_kernel = 1;  // 1 = int8 MFMA formulation of the sweep's fast path, 0 = VALU xor + popcount
     int pdq_kernel = 1;  // 0 = always generic; 1 / 2 = fused 512x512x3 kernel (64- / 128-px strips) where it applies
 };
@@ -54,6 +55,8 @@ int rph_launch_synth_images(uint8_t *d_out, uint64_t first_k, uint32_t n, uint32
                             hipStream_t stream);
 int rph_launch_synth_hashes(uint8_t *d_out, uint64_t first, uint64_t count, uint64_t n_total, uint64_t seed,
                             uint64_t n_clusters, hipStream_t stream);
+
+int rph_launch_read_stream(const void *d_buf, size_t bytes, uint32_t *d_sink, hipStream_t stream);
 
 // batcher.cpp
 void rph_batcher_forget(rph_ctx *ctx);

@@ -278,6 +278,10 @@ class Engine:
         return out
 
     # ---- device memory / events ----
+    def read_stream_dev(self, d_buf, nbytes, stream=None):
+        """one pure read pass over a device buffer (bench.py times it: the read bandwidth a streaming kernel can get)"""
+        check(self.L.rph_read_stream_dev(self.ctx, d_buf, nbytes, stream), "rph_read_stream_dev")
+
     def dev_alloc(self, nbytes):
         p = C.c_void_p()
         check(self.L.rph_dev_alloc(self.ctx, nbytes, C.byref(p)), "rph_dev_alloc")

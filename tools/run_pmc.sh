@@ -8,10 +8,14 @@ mkdir -p $OUT
 i=0
 while read -r p; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv --pmc $p -d $OUT/pass$i -o run -- python3 $R/bench.py --steps 1 --warmup 0 --images 30000 --hashes 1000000 --no-cpu-baseline > $OUT/pass$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv --pmc $p -d $OUT/pass$i -o run -- python3 $R/bench.py --steps 1 --warmup 0 --images 30000 --hashes 1000000 --no-cpu-baseline $2 > $OUT/pass$i.log 2>&1
 done <<'LIST'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU
 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IFETCH
 SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_IFETCH_LEVEL SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_BUSY_CU_CYCLES
+FETCH_SIZE
+WRITE_SIZE
+TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE
 LIST
 python3 $R/tools/pmc_summary.py $OUT pdq_fused512 hamming_mfma
