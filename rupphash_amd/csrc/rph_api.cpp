@@ -115,6 +115,14 @@ static int sweep_growing(uint64_t n, std::vector<rph_edge> &edges, F &&run)
     return RPH_ERR_CAPACITY;
 }
 
+// 1/3/4 channels, rows do not overlap, images do not overlap (a single image needs no image_stride)
+static bool pdq_geometry_ok(uint32_t n, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride, size_t image_stride)
+{
+    if (channels != 1 && channels != 3 && channels != 4) return false;
+    if (row_stride < (size_t)w * channels) return false;
+    return n <= 1 || image_stride >= row_stride * (h ? h - 1 : 0) + (size_t)w * channels;
+}
+
 extern "C" {
 
 int rph_abi_version(void) { return RPH_ABI_VERSION; }
@@ -220,8 +228,7 @@ int rph_pdq_hash_batch_dev(rph_ctx *ctx, const void *d_px, uint32_t n, uint32_t 
                            size_t row_stride, size_t image_stride, void *d_hash32, void *d_quality, void *d_coeffs,
                            void *d_dihedral, void *d_valid, void *stream)
 {
-    if (!ctx || (!d_px && n) || !d_hash32 || (channels != 1 && channels != 3 && channels != 4) ||
-        row_stride < (size_t)w * channels || image_stride < row_stride * (h ? h - 1 : 0) + (size_t)w * channels) {
+    if (!ctx || (!d_px && n) || !d_hash32 || !pdq_geometry_ok(n, w, h, channels, row_stride, image_stride)) {
         rph_set_error("rph_pdq_hash_batch: invalid argument (n=%u %ux%ux%u row_stride=%zu image_stride=%zu)", n, w, h,
                       channels, row_stride, image_stride);
         return RPH_ERR_INVALID_ARG;
@@ -261,9 +268,15 @@ int rph_pdq_hash_batch(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, 
         return RPH_ERR_INVALID_ARG;
     }
     if (n == 0) return RPH_OK;
+    if (!pdq_geometry_ok(n, w, h, channels, row_stride, image_stride)) {
+        rph_set_error("rph_pdq_hash_batch: invalid argument (n=%u %ux%ux%u row_stride=%zu image_stride=%zu)", n, w, h, channels,
+                      row_stride, image_stride);
+        return RPH_ERR_INVALID_ARG;
+    }
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
     // stage in chunks of <= 1 GiB of pixels
-    const size_t per = image_stride ? image_stride : 1;
+    const size_t one_image = (size_t)(h ? h - 1 : 0) * row_stride + (size_t)w * channels;
+    const size_t per = n > 1 ? image_stride : std::max<size_t>(one_image, 1);
     uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / per);
     chunk = std::min(chunk, n);
     DevBuf d_px, d_hash, d_q, d_c, d_d, d_v;
@@ -276,11 +289,10 @@ int rph_pdq_hash_batch(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, 
     for (uint32_t first = 0; first < n; first += chunk) {
         const uint32_t m = std::min(chunk, n - first);
         // the last image may be shorter than image_stride in the caller's buffer
-        const size_t last_bytes = (size_t)(h ? h - 1 : 0) * row_stride + (size_t)w * channels;
-        const size_t bytes = (size_t)(m - 1) * per + last_bytes;
+        const size_t bytes = (size_t)(m - 1) * per + one_image;
         RPH_HIP_CHECK(hipMemcpyAsync(d_px.p, px + (size_t)first * per, bytes, hipMemcpyHostToDevice, ctx->stream));
-        RPH_TRY(rph_pdq_hash_batch_dev(ctx, d_px.p, m, w, h, channels, row_stride, image_stride, d_hash.p, d_q.p, d_c.p,
-                                       d_d.p, d_v.p, ctx->stream));
+        RPH_TRY(rph_pdq_hash_batch_dev(ctx, d_px.p, m, w, h, channels, row_stride, per, d_hash.p, d_q.p, d_c.p, d_d.p, d_v.p,
+                                       ctx->stream));
         RPH_HIP_CHECK(hipMemcpyAsync(hash32_out + (size_t)first * 32, d_hash.p, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->stream));
         if (quality_out) RPH_HIP_CHECK(hipMemcpyAsync(quality_out + first, d_q.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (coeffs_out)

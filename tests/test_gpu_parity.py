@@ -566,3 +566,77 @@ def test_hash_one_single_caller_and_bad_args(eng, oracle):
     assert eng.L.rph_pdq_hash_one(eng.ctx, img.ctypes.data, 512, 512, 3, 100, hash32.ctypes.data, None, None, None) == _lib.RPH_ERR_INVALID_ARG
     assert eng.L.rph_pdq_batcher_config(eng.ctx, 0, 10) == _lib.RPH_ERR_INVALID_ARG
     eng.pdq_batcher_config()
+
+
+# ---- strided inputs: row_stride / image_stride are part of the C ABI (a decoder's padded rows, a sub-rectangle of an atlas)
+def _strided_batch(rng, n, h, w, ch, row_stride, image_stride):
+    """n images embedded in one byte buffer filled with noise; returns (buffer, list of contiguous images)"""
+    buf = rng.integers(0, 256, image_stride * (n - 1) + row_stride * (h - 1) + w * ch + 7, dtype=np.uint8)
+    imgs = []
+    for k in range(n):
+        rows = [buf[k * image_stride + y * row_stride: k * image_stride + y * row_stride + w * ch] for y in range(h)]
+        img = np.stack(rows)
+        imgs.append(img.reshape(h, w, ch) if ch > 1 else img.reshape(h, w))
+    return buf, imgs
+
+
+@pytest.mark.parametrize("w,h,ch,row_pad,img_pad,which", [
+    (512, 512, 3, 64, 4096, 1),    # fused strip64 with padded rows and a gap between images
+    (512, 512, 3, 128, 0, 2),      # fused strip128, rows padded, images back to back
+    (512, 512, 3, 1, 3, 1),        # row stride 1537: not a multiple of 4 -> generic kernel must take over
+    (100, 37, 3, 5, 11, 1),        # generic kernel
+    (64, 64, 1, 3, 0, 1),          # Luma8
+    (200, 300, 4, 8, 16, 1),       # RGBA
+    (780, 768, 3, 12, 100, 1),     # pre-downsample path
+])
+def test_pdq_strided_inputs_match_oracle(eng, oracle, w, h, ch, row_pad, img_pad, which):
+    rng = np.random.default_rng(w * 7 + h + ch + row_pad)
+    n = 3
+    row_stride = w * ch + row_pad
+    image_stride = row_stride * h + img_pad
+    buf, imgs = _strided_batch(rng, n, h, w, ch, row_stride, image_stride)
+    from rupphash_amd._lib import check
+    hashes = np.zeros((n, 32), np.uint8)
+    quality = np.zeros(n, np.float32)
+    coeffs = np.zeros((n, 256), np.float32)
+    valid = np.zeros(n, np.uint8)
+    eng.set_pdq_kernel(which)
+    try:
+        # host entry point
+        check(eng.L.rph_pdq_hash_batch(eng.ctx, buf.ctypes.data, n, w, h, ch, row_stride, image_stride, hashes.ctypes.data,
+                                       quality.ctypes.data, coeffs.ctypes.data, None, valid.ctypes.data), "rph_pdq_hash_batch")
+        # device entry point on the same bytes
+        d_px = eng.dev_alloc(buf.nbytes)
+        d_h = eng.dev_alloc(n * 32)
+        try:
+            eng.dev_upload(d_px, buf)
+            eng.pdq_hash_batch_dev(d_px, n, w, h, ch, d_h, row_stride=row_stride, image_stride=image_stride)
+            eng.synchronize()
+            dev_hashes = np.zeros((n, 32), np.uint8)
+            eng.dev_download(dev_hashes, d_h)
+        finally:
+            eng.dev_free(d_px)
+            eng.dev_free(d_h)
+    finally:
+        eng.set_pdq_kernel(1)
+    assert np.array_equal(dev_hashes, hashes)
+    for k in range(n):
+        rc, c, q = oracle.pdq_features(imgs[k])
+        assert rc == 0 and valid[k] == 1
+        assert np.array_equal(bits(coeffs[k]), bits(c)), k
+        assert bits(quality[k:k + 1])[0] == bits(np.float32(q))[()]
+        assert np.array_equal(hashes[k], oracle.to_hash(c))
+
+
+def test_pdq_bad_strides_are_rejected(eng):
+    from rupphash_amd import _lib
+    img = np.zeros((64, 64, 3), np.uint8)
+    h32 = np.zeros(32, np.uint8)
+    f = eng.L.rph_pdq_hash_batch
+    assert f(eng.ctx, img.ctypes.data, 1, 64, 64, 3, 191, 64 * 192, h32.ctypes.data, None, None, None, None) == _lib.RPH_ERR_INVALID_ARG  # row_stride < w*ch
+    assert f(eng.ctx, img.ctypes.data, 2, 64, 64, 3, 192, 100, h32.ctypes.data, None, None, None, None) == _lib.RPH_ERR_INVALID_ARG      # images overlap
+    assert f(eng.ctx, None, 1, 64, 64, 3, 192, 64 * 192, h32.ctypes.data, None, None, None, None) == _lib.RPH_ERR_INVALID_ARG
+    assert f(eng.ctx, img.ctypes.data, 1, 64, 64, 2, 128, 64 * 128, h32.ctypes.data, None, None, None, None) in (_lib.RPH_ERR_INVALID_ARG, _lib.RPH_ERR_UNSUPPORTED)
+    assert b"" != eng.L.rph_last_error()
+    # a single image needs no image_stride at all
+    assert f(eng.ctx, img.ctypes.data, 1, 64, 64, 3, 192, 0, h32.ctypes.data, None, None, None, None) == _lib.RPH_OK
