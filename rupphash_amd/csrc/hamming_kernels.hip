@@ -211,6 +211,12 @@ __device__ __forceinline__ uint2 expand_byte(uint32_t v)
     return r;
 }
 
+__device__ __forceinline__ int max3i(int a, int b, int c)
+{
+    const int ab = a > b ? a : b;
+    return ab > c ? ab : c;
+}
+
 template <int PW>
 __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
 {
@@ -312,9 +318,11 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
 #pragma unroll
                 for (int kb = 0; kb < PW; kb++) B[kb] = *reinterpret_cast<const v4i *>(bp + kb * 16);
                 auto screen = [&](const v16i &acc, int rb) {
-                    int m = acc[0];
-#pragma unroll
-                    for (int r = 1; r < 16; r++) m = acc[r] > m ? acc[r] : m;
+                    // max of the 16 accumulators as a tree of v_max3_i32 (depth 3): a linear chain of dependent VALU instructions
+                    // issues at ~9 clk each from one wave (tools/valu_dep.hip), independent ones at ~5.6
+                    const int m0 = max3i(acc[0], acc[1], acc[2]), m1 = max3i(acc[3], acc[4], acc[5]), m2 = max3i(acc[6], acc[7], acc[8]);
+                    const int m3 = max3i(acc[9], acc[10], acc[11]), m4 = max3i(acc[12], acc[13], acc[14]);
+                    const int m = max3i(max3i(m0, m1, m2), max3i(m3, m4, acc[15]), m0);
                     if (m >= thresh_dot) {  // rare
 #pragma unroll
                         for (int r = 0; r < 16; r++) {
