@@ -316,7 +316,36 @@ def main():
         t0 = time.perf_counter()
         groups, cmp_count = eng.group_files_pdq(fh, 40, coeffs=coeffs, quality=qual)
         t_group = time.perf_counter() - t0
+        # (3) pdqhash.rs:659-712 / NOTES.txt:41-46: bench_pdq_performance on the reference's tests/bench.jpg (1280x854):
+        #     100 x generate_pdq_features one image per call, and 30 000 x generate_dihedral_hashes
+        bench_jpg = None
+        jpg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "bench.jpg")
+        try:
+            from PIL import Image
+            photo = np.asarray(Image.open(jpg).convert("RGB"))
+        except Exception as e:  # Pillow or the fixture missing: the case is simply not reported
+            photo = None
+            bench_jpg = {"skipped": repr(e)}
+        if photo is not None:
+            eng.pdq_batcher_config(max_batch=1, max_wait_us=0)
+            one = eng.pdq_hash_one(photo)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                eng.pdq_hash_one(photo)
+            t_one = (time.perf_counter() - t0) / 100
+            eng.pdq_batcher_config()
+            many = np.repeat(one[2][None, :], 30000, axis=0)
+            eng.pdq_hashes_from_coeffs(many[:64])
+            t0 = time.perf_counter()
+            eng.pdq_hashes_from_coeffs(many, want_hash=False, want_dihedral=True)
+            t_dih = time.perf_counter() - t0
+            bench_jpg = {"generate_pdq_features_ms_per_call": t_one * 1e3, "image": "1280x854 RGB8 from host memory, one image per call "
+                         "(H2D of 3.3 MB, GPU luma + box pre-downsample to 512x342, PDQ, D2H), decode excluded as in the reference",
+                         "reference_published_ms_per_call": 4.286,
+                         "generate_dihedral_hashes_30000_s": t_dih, "reference_published_30000_s": 0.2957,
+                         "reference_source": "NOTES.txt:41-46 (one thread, unstated CPU)"}
         result["reference_cases"] = {
+            "bench_pdq_performance_bench_jpg": bench_jpg,
             "find_groups_1M_u64_max_dist_5": {"seconds": t_u64, "groups": len(g64), "includes": "H2D copy, all-pairs sweep, host greedy clustering",
                                               "reference_published_seconds": 12.27, "reference_source": "NOTES.txt:19 (14 threads, unstated CPU)"},
             "group_500k_files_pdq_similarity_40": {"seconds": t_group, "groups": len(groups), "comparison_count": int(cmp_count),
