@@ -143,35 +143,37 @@ const char *rph_status_string(int s)
 
 int rph_init(int device, rph_ctx **out)
 {
-    if (!out) return RPH_ERR_INVALID_ARG;
-    *out = nullptr;
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
-        rph_set_error("rph_init: no HIP device visible (this library has no CPU fallback)");
-        return RPH_ERR_NO_DEVICE;
-    }
-    if (device < 0 || device >= count) {
-        rph_set_error("rph_init: device %d out of range (%d visible)", device, count);
-        return RPH_ERR_NO_DEVICE;
-    }
-    hipDeviceProp_t prop;
-    RPH_HIP_CHECK(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        rph_set_error("rph_init: device %d is %s; this build targets gfx950 (MI355X) only", device, prop.gcnArchName);
-        return RPH_ERR_NO_DEVICE;
-    }
-    RPH_HIP_CHECK(hipSetDevice(device));
-    rph_ctx *ctx = new rph_ctx();
-    ctx->device = device;
-    ctx->compute_units = prop.multiProcessorCount;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        rph_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
-        delete ctx;
-        return RPH_ERR_HIP;
-    }
-    *out = ctx;
-    return RPH_OK;
+    return rph_guarded("rph_init", [&]() -> int {
+        if (!out) return RPH_ERR_INVALID_ARG;
+        *out = nullptr;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+            rph_set_error("rph_init: no HIP device visible (this library has no CPU fallback)");
+            return RPH_ERR_NO_DEVICE;
+        }
+        if (device < 0 || device >= count) {
+            rph_set_error("rph_init: device %d out of range (%d visible)", device, count);
+            return RPH_ERR_NO_DEVICE;
+        }
+        hipDeviceProp_t prop;
+        RPH_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            rph_set_error("rph_init: device %d is %s; this build targets gfx950 (MI355X) only", device, prop.gcnArchName);
+            return RPH_ERR_NO_DEVICE;
+        }
+        RPH_HIP_CHECK(hipSetDevice(device));
+        rph_ctx *ctx = new rph_ctx();
+        ctx->device = device;
+        ctx->compute_units = prop.multiProcessorCount;
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            rph_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete ctx;
+            return RPH_ERR_HIP;
+        }
+        *out = ctx;
+        return RPH_OK;
+    });
 }
 
 int rph_shutdown(rph_ctx *ctx)
@@ -263,46 +265,48 @@ int rph_pdq_hash_batch(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, 
                        size_t row_stride, size_t image_stride, uint8_t *hash32_out, float *quality_out, float *coeffs_out,
                        uint8_t *dihedral_out, uint8_t *valid_out)
 {
-    if (!ctx || (!px && n) || !hash32_out) {
-        rph_set_error("rph_pdq_hash_batch: null argument");
-        return RPH_ERR_INVALID_ARG;
-    }
-    if (n == 0) return RPH_OK;
-    if (!pdq_geometry_ok(n, w, h, channels, row_stride, image_stride)) {
-        rph_set_error("rph_pdq_hash_batch: invalid argument (n=%u %ux%ux%u row_stride=%zu image_stride=%zu)", n, w, h, channels,
-                      row_stride, image_stride);
-        return RPH_ERR_INVALID_ARG;
-    }
-    RPH_HIP_CHECK(hipSetDevice(ctx->device));
-    // stage in chunks of <= 1 GiB of pixels
-    const size_t one_image = (size_t)(h ? h - 1 : 0) * row_stride + (size_t)w * channels;
-    const size_t per = n > 1 ? image_stride : std::max<size_t>(one_image, 1);
-    uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / per);
-    chunk = std::min(chunk, n);
-    DevBuf d_px, d_hash, d_q, d_c, d_d, d_v;
-    RPH_TRY(d_px.alloc(per * chunk));
-    RPH_TRY(d_hash.alloc((size_t)chunk * 32));
-    if (quality_out) RPH_TRY(d_q.alloc((size_t)chunk * 4));
-    if (coeffs_out) RPH_TRY(d_c.alloc((size_t)chunk * 1024));
-    if (dihedral_out) RPH_TRY(d_d.alloc((size_t)chunk * 256));
-    if (valid_out) RPH_TRY(d_v.alloc(chunk));
-    for (uint32_t first = 0; first < n; first += chunk) {
-        const uint32_t m = std::min(chunk, n - first);
-        // the last image may be shorter than image_stride in the caller's buffer
-        const size_t bytes = (size_t)(m - 1) * per + one_image;
-        RPH_HIP_CHECK(hipMemcpyAsync(d_px.p, px + (size_t)first * per, bytes, hipMemcpyHostToDevice, ctx->stream));
-        RPH_TRY(rph_pdq_hash_batch_dev(ctx, d_px.p, m, w, h, channels, row_stride, per, d_hash.p, d_q.p, d_c.p, d_d.p, d_v.p,
-                                       ctx->stream));
-        RPH_HIP_CHECK(hipMemcpyAsync(hash32_out + (size_t)first * 32, d_hash.p, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->stream));
-        if (quality_out) RPH_HIP_CHECK(hipMemcpyAsync(quality_out + first, d_q.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (coeffs_out)
-            RPH_HIP_CHECK(hipMemcpyAsync(coeffs_out + (size_t)first * 256, d_c.p, (size_t)m * 1024, hipMemcpyDeviceToHost, ctx->stream));
-        if (dihedral_out)
-            RPH_HIP_CHECK(hipMemcpyAsync(dihedral_out + (size_t)first * 256, d_d.p, (size_t)m * 256, hipMemcpyDeviceToHost, ctx->stream));
-        if (valid_out) RPH_HIP_CHECK(hipMemcpyAsync(valid_out + first, d_v.p, m, hipMemcpyDeviceToHost, ctx->stream));
-        RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    }
-    return RPH_OK;
+    return rph_guarded("rph_pdq_hash_batch", [&]() -> int {
+        if (!ctx || (!px && n) || !hash32_out) {
+            rph_set_error("rph_pdq_hash_batch: null argument");
+            return RPH_ERR_INVALID_ARG;
+        }
+        if (n == 0) return RPH_OK;
+        if (!pdq_geometry_ok(n, w, h, channels, row_stride, image_stride)) {
+            rph_set_error("rph_pdq_hash_batch: invalid argument (n=%u %ux%ux%u row_stride=%zu image_stride=%zu)", n, w, h, channels,
+                          row_stride, image_stride);
+            return RPH_ERR_INVALID_ARG;
+        }
+        RPH_HIP_CHECK(hipSetDevice(ctx->device));
+        // stage in chunks of <= 1 GiB of pixels
+        const size_t one_image = (size_t)(h ? h - 1 : 0) * row_stride + (size_t)w * channels;
+        const size_t per = n > 1 ? image_stride : std::max<size_t>(one_image, 1);
+        uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / per);
+        chunk = std::min(chunk, n);
+        DevBuf d_px, d_hash, d_q, d_c, d_d, d_v;
+        RPH_TRY(d_px.alloc(per * chunk));
+        RPH_TRY(d_hash.alloc((size_t)chunk * 32));
+        if (quality_out) RPH_TRY(d_q.alloc((size_t)chunk * 4));
+        if (coeffs_out) RPH_TRY(d_c.alloc((size_t)chunk * 1024));
+        if (dihedral_out) RPH_TRY(d_d.alloc((size_t)chunk * 256));
+        if (valid_out) RPH_TRY(d_v.alloc(chunk));
+        for (uint32_t first = 0; first < n; first += chunk) {
+            const uint32_t m = std::min(chunk, n - first);
+            // the last image may be shorter than image_stride in the caller's buffer
+            const size_t bytes = (size_t)(m - 1) * per + one_image;
+            RPH_HIP_CHECK(hipMemcpyAsync(d_px.p, px + (size_t)first * per, bytes, hipMemcpyHostToDevice, ctx->stream));
+            RPH_TRY(rph_pdq_hash_batch_dev(ctx, d_px.p, m, w, h, channels, row_stride, per, d_hash.p, d_q.p, d_c.p, d_d.p, d_v.p,
+                                           ctx->stream));
+            RPH_HIP_CHECK(hipMemcpyAsync(hash32_out + (size_t)first * 32, d_hash.p, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->stream));
+            if (quality_out) RPH_HIP_CHECK(hipMemcpyAsync(quality_out + first, d_q.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (coeffs_out)
+                RPH_HIP_CHECK(hipMemcpyAsync(coeffs_out + (size_t)first * 256, d_c.p, (size_t)m * 1024, hipMemcpyDeviceToHost, ctx->stream));
+            if (dihedral_out)
+                RPH_HIP_CHECK(hipMemcpyAsync(dihedral_out + (size_t)first * 256, d_d.p, (size_t)m * 256, hipMemcpyDeviceToHost, ctx->stream));
+            if (valid_out) RPH_HIP_CHECK(hipMemcpyAsync(valid_out + first, d_v.p, m, hipMemcpyDeviceToHost, ctx->stream));
+            RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        return RPH_OK;
+    });
 }
 
 int rph_pdq_hashes_from_coeffs_dev(rph_ctx *ctx, const void *d_coeffs, uint32_t n, void *d_hash32, void *d_dihedral,
@@ -318,22 +322,24 @@ int rph_pdq_hashes_from_coeffs_dev(rph_ctx *ctx, const void *d_coeffs, uint32_t 
 
 int rph_pdq_hashes_from_coeffs(rph_ctx *ctx, const float *coeffs, uint32_t n, uint8_t *hash32_out, uint8_t *dihedral_out)
 {
-    if (!ctx || (!coeffs && n) || (!hash32_out && !dihedral_out)) {
-        rph_set_error("rph_pdq_hashes_from_coeffs: null argument");
-        return RPH_ERR_INVALID_ARG;
-    }
-    if (n == 0) return RPH_OK;
-    RPH_HIP_CHECK(hipSetDevice(ctx->device));
-    DevBuf d_c, d_h, d_d;
-    RPH_TRY(d_c.alloc((size_t)n * 1024));
-    if (hash32_out) RPH_TRY(d_h.alloc((size_t)n * 32));
-    if (dihedral_out) RPH_TRY(d_d.alloc((size_t)n * 256));
-    RPH_HIP_CHECK(hipMemcpyAsync(d_c.p, coeffs, (size_t)n * 1024, hipMemcpyHostToDevice, ctx->stream));
-    RPH_TRY(rph_pdq_hashes_from_coeffs_dev(ctx, d_c.p, n, d_h.p, d_d.p, ctx->stream));
-    if (hash32_out) RPH_HIP_CHECK(hipMemcpyAsync(hash32_out, d_h.p, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    if (dihedral_out) RPH_HIP_CHECK(hipMemcpyAsync(dihedral_out, d_d.p, (size_t)n * 256, hipMemcpyDeviceToHost, ctx->stream));
-    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return RPH_OK;
+    return rph_guarded("rph_pdq_hashes_from_coeffs", [&]() -> int {
+        if (!ctx || (!coeffs && n) || (!hash32_out && !dihedral_out)) {
+            rph_set_error("rph_pdq_hashes_from_coeffs: null argument");
+            return RPH_ERR_INVALID_ARG;
+        }
+        if (n == 0) return RPH_OK;
+        RPH_HIP_CHECK(hipSetDevice(ctx->device));
+        DevBuf d_c, d_h, d_d;
+        RPH_TRY(d_c.alloc((size_t)n * 1024));
+        if (hash32_out) RPH_TRY(d_h.alloc((size_t)n * 32));
+        if (dihedral_out) RPH_TRY(d_d.alloc((size_t)n * 256));
+        RPH_HIP_CHECK(hipMemcpyAsync(d_c.p, coeffs, (size_t)n * 1024, hipMemcpyHostToDevice, ctx->stream));
+        RPH_TRY(rph_pdq_hashes_from_coeffs_dev(ctx, d_c.p, n, d_h.p, d_d.p, ctx->stream));
+        if (hash32_out) RPH_HIP_CHECK(hipMemcpyAsync(hash32_out, d_h.p, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (dihedral_out) RPH_HIP_CHECK(hipMemcpyAsync(dihedral_out, d_d.p, (size_t)n * 256, hipMemcpyDeviceToHost, ctx->stream));
+        RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return RPH_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -369,19 +375,23 @@ int rph_hamming_variant_pairs_dev(rph_ctx *ctx, const void *d_variants, uint32_t
 int rph_hamming_all_pairs(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t threshold, uint32_t part,
                           uint32_t nparts, rph_edge *edges, uint64_t cap, uint64_t *n_edges_out)
 {
-    return sweep_host(ctx, nullptr, 1, hashes32, nullptr, nullptr, n, threshold, part, nparts, edges, cap, n_edges_out);
+    return rph_guarded("rph_hamming_all_pairs", [&]() -> int {
+        return sweep_host(ctx, nullptr, 1, hashes32, nullptr, nullptr, n, threshold, part, nparts, edges, cap, n_edges_out);
+    });
 }
 
 int rph_hamming_variant_pairs(rph_ctx *ctx, const uint8_t *variants, uint32_t n_variants, const uint8_t *hashes32,
                               const uint8_t *low_conf, uint64_t n, uint32_t similarity, uint32_t part, uint32_t nparts,
                               rph_edge *edges, uint64_t cap, uint64_t *n_edges_out)
 {
-    if (!variants && n) {
-        rph_set_error("rph_hamming_variant_pairs: variants is null");
-        return RPH_ERR_INVALID_ARG;
-    }
-    return sweep_host(ctx, variants, n_variants, hashes32, low_conf, nullptr, n, similarity, part, nparts, edges, cap,
-                      n_edges_out);
+    return rph_guarded("rph_hamming_variant_pairs", [&]() -> int {
+        if (!variants && n) {
+            rph_set_error("rph_hamming_variant_pairs: variants is null");
+            return RPH_ERR_INVALID_ARG;
+        }
+        return sweep_host(ctx, variants, n_variants, hashes32, low_conf, nullptr, n, similarity, part, nparts, edges, cap,
+                          n_edges_out);
+    });
 }
 
 int rph_hamming_all_pairs64_dev(rph_ctx *ctx, const void *d_hashes64, uint64_t n, uint32_t threshold, uint32_t part,
@@ -399,153 +409,167 @@ int rph_hamming_all_pairs64_dev(rph_ctx *ctx, const void *d_hashes64, uint64_t n
 int rph_hamming_all_pairs64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, uint32_t threshold, uint32_t part,
                             uint32_t nparts, rph_edge *edges, uint64_t cap, uint64_t *n_edges_out)
 {
-    if (!ctx || (!hashes64 && n) || !n_edges_out || (!edges && cap)) {
-        rph_set_error("rph_hamming_all_pairs64: null argument");
-        return RPH_ERR_INVALID_ARG;
-    }
-    *n_edges_out = 0;
-    if (n < 2) return RPH_OK;
-    RPH_HIP_CHECK(hipSetDevice(ctx->device));
-    DevBuf d_h, d_e, d_cnt;
-    RPH_TRY(d_h.alloc(n * 8));
-    RPH_TRY(d_e.alloc(cap * sizeof(rph_edge)));
-    RPH_TRY(d_cnt.alloc(8));
-    RPH_HIP_CHECK(hipMemcpyAsync(d_h.p, hashes64, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    RPH_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, 8, ctx->stream));
-    RPH_TRY(rph_launch_hamming64_sweep((const uint64_t *)d_h.p, n, threshold, part, nparts, (rph_edge *)d_e.p, cap,
-                                       (unsigned long long *)d_cnt.p, ctx->stream));
-    unsigned long long cnt = 0;
-    RPH_HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    *n_edges_out = cnt;
-    const uint64_t take = std::min<uint64_t>(cnt, cap);
-    if (take) RPH_HIP_CHECK(hipMemcpy(edges, d_e.p, take * sizeof(rph_edge), hipMemcpyDeviceToHost));
-    if (cnt > cap) {
-        rph_set_error("hamming64 sweep: %llu edges found, capacity %llu", cnt, (unsigned long long)cap);
-        return RPH_ERR_CAPACITY;
-    }
-    return RPH_OK;
+    return rph_guarded("rph_hamming_all_pairs64", [&]() -> int {
+        if (!ctx || (!hashes64 && n) || !n_edges_out || (!edges && cap)) {
+            rph_set_error("rph_hamming_all_pairs64: null argument");
+            return RPH_ERR_INVALID_ARG;
+        }
+        *n_edges_out = 0;
+        if (n < 2) return RPH_OK;
+        RPH_HIP_CHECK(hipSetDevice(ctx->device));
+        DevBuf d_h, d_e, d_cnt;
+        RPH_TRY(d_h.alloc(n * 8));
+        RPH_TRY(d_e.alloc(cap * sizeof(rph_edge)));
+        RPH_TRY(d_cnt.alloc(8));
+        RPH_HIP_CHECK(hipMemcpyAsync(d_h.p, hashes64, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        RPH_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, 8, ctx->stream));
+        RPH_TRY(rph_launch_hamming64_sweep((const uint64_t *)d_h.p, n, threshold, part, nparts, (rph_edge *)d_e.p, cap,
+                                           (unsigned long long *)d_cnt.p, ctx->stream));
+        unsigned long long cnt = 0;
+        RPH_HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        *n_edges_out = cnt;
+        const uint64_t take = std::min<uint64_t>(cnt, cap);
+        if (take) RPH_HIP_CHECK(hipMemcpy(edges, d_e.p, take * sizeof(rph_edge), hipMemcpyDeviceToHost));
+        if (cnt > cap) {
+            rph_set_error("hamming64 sweep: %llu edges found, capacity %llu", cnt, (unsigned long long)cap);
+            return RPH_ERR_CAPACITY;
+        }
+        return RPH_OK;
+    });
 }
 
 int rph_find_groups64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, uint32_t max_dist, uint32_t *members,
                       uint32_t *offsets, uint32_t *n_groups_out)
 {
-    if (!ctx || (!hashes64 && n) || !members || !offsets || !n_groups_out) {
-        rph_set_error("rph_find_groups64: null argument");
-        return RPH_ERR_INVALID_ARG;
-    }
-    *n_groups_out = 0;
-    offsets[0] = 0;
-    if (n < 2) return RPH_OK;
-    std::vector<rph_edge> edges;
-    RPH_TRY(sweep_growing(n, edges, [&](rph_edge *e, uint64_t cap, uint64_t *found) {
-        return rph_hamming_all_pairs64(ctx, hashes64, n, max_dist, 0, 1, e, cap, found);
-    }));
-    return rph_host_find_groups(edges.data(), edges.size(), n, members, offsets, n_groups_out);
+    return rph_guarded("rph_find_groups64", [&]() -> int {
+        if (!ctx || (!hashes64 && n) || !members || !offsets || !n_groups_out) {
+            rph_set_error("rph_find_groups64: null argument");
+            return RPH_ERR_INVALID_ARG;
+        }
+        *n_groups_out = 0;
+        offsets[0] = 0;
+        if (n < 2) return RPH_OK;
+        std::vector<rph_edge> edges;
+        RPH_TRY(sweep_growing(n, edges, [&](rph_edge *e, uint64_t cap, uint64_t *found) {
+            return rph_hamming_all_pairs64(ctx, hashes64, n, max_dist, 0, 1, e, cap, found);
+        }));
+        return rph_host_find_groups(edges.data(), edges.size(), n, members, offsets, n_groups_out);
+    });
 }
 
 int rph_find_groups_from_edges(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,
                                uint32_t *n_groups_out)
 {
-    if ((!edges && n_edges) || !members || !offsets || !n_groups_out) return RPH_ERR_INVALID_ARG;
-    return rph_host_find_groups(edges, n_edges, n, members, offsets, n_groups_out);
+    return rph_guarded("rph_find_groups_from_edges", [&]() -> int {
+        if ((!edges && n_edges) || !members || !offsets || !n_groups_out) return RPH_ERR_INVALID_ARG;
+        return rph_host_find_groups(edges, n_edges, n, members, offsets, n_groups_out);
+    });
 }
 
 int rph_union_find_groups(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,
                           uint32_t *n_groups_out)
 {
-    if ((!edges && n_edges) || !members || !offsets || !n_groups_out) return RPH_ERR_INVALID_ARG;
-    return rph_host_union_find(edges, n_edges, n, members, offsets, n_groups_out);
+    return rph_guarded("rph_union_find_groups", [&]() -> int {
+        if ((!edges && n_edges) || !members || !offsets || !n_groups_out) return RPH_ERR_INVALID_ARG;
+        return rph_host_union_find(edges, n_edges, n, members, offsets, n_groups_out);
+    });
 }
 
 int rph_find_groups256(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t max_dist, uint32_t *members,
                        uint32_t *offsets, uint32_t *n_groups_out)
 {
-    if (!ctx || (!hashes32 && n) || !members || !offsets || !n_groups_out) {
-        rph_set_error("rph_find_groups256: null argument");
-        return RPH_ERR_INVALID_ARG;
-    }
-    *n_groups_out = 0;
-    offsets[0] = 0;
-    if (n < 2) return RPH_OK;
-    std::vector<rph_edge> edges;
-    RPH_TRY(sweep_growing(n, edges, [&](rph_edge *e, uint64_t cap, uint64_t *found) {
-        return sweep_host(ctx, nullptr, 1, hashes32, nullptr, nullptr, n, max_dist, 0, 1, e, cap, found);
-    }));
-    return rph_host_find_groups(edges.data(), edges.size(), n, members, offsets, n_groups_out);
+    return rph_guarded("rph_find_groups256", [&]() -> int {
+        if (!ctx || (!hashes32 && n) || !members || !offsets || !n_groups_out) {
+            rph_set_error("rph_find_groups256: null argument");
+            return RPH_ERR_INVALID_ARG;
+        }
+        *n_groups_out = 0;
+        offsets[0] = 0;
+        if (n < 2) return RPH_OK;
+        std::vector<rph_edge> edges;
+        RPH_TRY(sweep_growing(n, edges, [&](rph_edge *e, uint64_t cap, uint64_t *found) {
+            return sweep_host(ctx, nullptr, 1, hashes32, nullptr, nullptr, n, max_dist, 0, 1, e, cap, found);
+        }));
+        return rph_host_find_groups(edges.data(), edges.size(), n, members, offsets, n_groups_out);
+    });
 }
 
 int rph_group_files_pdq(rph_ctx *ctx, const uint8_t *hashes32, const float *coeffs, const uint8_t *has_features,
                         const int32_t *quality, uint64_t n, uint32_t similarity, uint32_t *members, uint32_t *offsets,
                         uint32_t *n_groups_out, uint64_t *comparison_count_out)
 {
-    if (!ctx || (!hashes32 && n) || !members || !offsets || !n_groups_out) {
-        rph_set_error("rph_group_files_pdq: null argument");
-        return RPH_ERR_INVALID_ARG;
-    }
-    if (similarity > RPH_MAX_SIMILARITY_256) {
-        // scanner.rs:1650-1655 asserts this
-        rph_set_error("Similarity distances above %u require R=4 bit-flip checks, which are not implemented.",
-                      RPH_MAX_SIMILARITY_256);
-        return RPH_ERR_INVALID_ARG;
-    }
-    *n_groups_out = 0;
-    offsets[0] = 0;
-    if (comparison_count_out) *comparison_count_out = 0;
-    if (n < 2) return RPH_OK;
-    RPH_HIP_CHECK(hipSetDevice(ctx->device));
-
-    std::vector<uint8_t> low_conf;
-    if (quality) {
-        low_conf.resize(n);
-        for (uint64_t i = 0; i < n; i++) low_conf[i] = (uint8_t)rph_is_low_pdq_quality(quality[i]);
-    }
-    // 8 dihedral variants per file from its coefficients (scanner.rs:1621-1623); files without
-    // features contribute their hash as the only variant (:1624-1627)
-    std::vector<uint8_t> variants;
-    if (coeffs) {
-        variants.resize(n * 256);
-        const uint32_t step = 1u << 20;
-        for (uint64_t first = 0; first < n; first += step) {
-            const uint32_t m = (uint32_t)std::min<uint64_t>(step, n - first);
-            RPH_TRY(rph_pdq_hashes_from_coeffs(ctx, coeffs + first * 256, m, nullptr, variants.data() + first * 256));
+    return rph_guarded("rph_group_files_pdq", [&]() -> int {
+        if (!ctx || (!hashes32 && n) || !members || !offsets || !n_groups_out) {
+            rph_set_error("rph_group_files_pdq: null argument");
+            return RPH_ERR_INVALID_ARG;
         }
-        if (has_features)
-            for (uint64_t i = 0; i < n; i++)
-                if (!has_features[i])
-                    for (int v = 0; v < 8; v++) std::memcpy(&variants[i * 256 + v * 32], hashes32 + i * 32, 32);
-    }
-    std::vector<rph_edge> edges;
-    RPH_TRY(sweep_growing(n, edges, [&](rph_edge *e, uint64_t cap, uint64_t *found) {
-        return sweep_host(ctx, coeffs ? variants.data() : nullptr, coeffs ? 8 : 1, hashes32,
-                          quality ? low_conf.data() : nullptr, (coeffs && has_features) ? has_features : nullptr, n, similarity,
-                          0, 1, e, cap, found);
-    }));
-    if (comparison_count_out) *comparison_count_out = edges.size();
-    return rph_host_union_find(edges.data(), edges.size(), n, members, offsets, n_groups_out);
+        if (similarity > RPH_MAX_SIMILARITY_256) {
+            // scanner.rs:1650-1655 asserts this
+            rph_set_error("Similarity distances above %u require R=4 bit-flip checks, which are not implemented.",
+                          RPH_MAX_SIMILARITY_256);
+            return RPH_ERR_INVALID_ARG;
+        }
+        *n_groups_out = 0;
+        offsets[0] = 0;
+        if (comparison_count_out) *comparison_count_out = 0;
+        if (n < 2) return RPH_OK;
+        RPH_HIP_CHECK(hipSetDevice(ctx->device));
+
+        std::vector<uint8_t> low_conf;
+        if (quality) {
+            low_conf.resize(n);
+            for (uint64_t i = 0; i < n; i++) low_conf[i] = (uint8_t)rph_is_low_pdq_quality(quality[i]);
+        }
+        // 8 dihedral variants per file from its coefficients (scanner.rs:1621-1623); files without
+        // features contribute their hash as the only variant (:1624-1627)
+        std::vector<uint8_t> variants;
+        if (coeffs) {
+            variants.resize(n * 256);
+            const uint32_t step = 1u << 20;
+            for (uint64_t first = 0; first < n; first += step) {
+                const uint32_t m = (uint32_t)std::min<uint64_t>(step, n - first);
+                RPH_TRY(rph_pdq_hashes_from_coeffs(ctx, coeffs + first * 256, m, nullptr, variants.data() + first * 256));
+            }
+            if (has_features)
+                for (uint64_t i = 0; i < n; i++)
+                    if (!has_features[i])
+                        for (int v = 0; v < 8; v++) std::memcpy(&variants[i * 256 + v * 32], hashes32 + i * 32, 32);
+        }
+        std::vector<rph_edge> edges;
+        RPH_TRY(sweep_growing(n, edges, [&](rph_edge *e, uint64_t cap, uint64_t *found) {
+            return sweep_host(ctx, coeffs ? variants.data() : nullptr, coeffs ? 8 : 1, hashes32,
+                              quality ? low_conf.data() : nullptr, (coeffs && has_features) ? has_features : nullptr, n, similarity,
+                              0, 1, e, cap, found);
+        }));
+        if (comparison_count_out) *comparison_count_out = edges.size();
+        return rph_host_union_find(edges.data(), edges.size(), n, members, offsets, n_groups_out);
+    });
 }
 
 int rph_mih_build256(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t *offsets, uint32_t *values)
 {
-    if (!ctx || (!hashes32 && n) || !offsets || (!values && n)) {
-        rph_set_error("rph_mih_build256: null argument");
-        return RPH_ERR_INVALID_ARG;
-    }
-    RPH_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t n_off = (size_t)16 * 65536 + 1;
-    DevBuf d_h, d_o, d_v;
-    RPH_TRY(d_h.alloc(n * 32));
-    RPH_TRY(d_o.alloc(n_off * 4));
-    RPH_TRY(d_v.alloc(n * 16 * 4));
-    RPH_HIP_CHECK(hipMemcpyAsync(d_h.p, hashes32, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        RPH_TRY(rph_launch_mih_build256(ctx, (const uint8_t *)d_h.p, n, (uint32_t *)d_o.p, (uint32_t *)d_v.p, ctx->stream));
-    }
-    RPH_HIP_CHECK(hipMemcpyAsync(offsets, d_o.p, n_off * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (n) RPH_HIP_CHECK(hipMemcpyAsync(values, d_v.p, n * 16 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return RPH_OK;
+    return rph_guarded("rph_mih_build256", [&]() -> int {
+        if (!ctx || (!hashes32 && n) || !offsets || (!values && n)) {
+            rph_set_error("rph_mih_build256: null argument");
+            return RPH_ERR_INVALID_ARG;
+        }
+        RPH_HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n_off = (size_t)16 * 65536 + 1;
+        DevBuf d_h, d_o, d_v;
+        RPH_TRY(d_h.alloc(n * 32));
+        RPH_TRY(d_o.alloc(n_off * 4));
+        RPH_TRY(d_v.alloc(n * 16 * 4));
+        RPH_HIP_CHECK(hipMemcpyAsync(d_h.p, hashes32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+        {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            RPH_TRY(rph_launch_mih_build256(ctx, (const uint8_t *)d_h.p, n, (uint32_t *)d_o.p, (uint32_t *)d_v.p, ctx->stream));
+        }
+        RPH_HIP_CHECK(hipMemcpyAsync(offsets, d_o.p, n_off * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (n) RPH_HIP_CHECK(hipMemcpyAsync(values, d_v.p, n * 16 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return RPH_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------

@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <exception>
 #include <mutex>
+#include <new>
 
 #include "../../include/rupphash.h"
 
@@ -57,6 +59,24 @@ int rph_launch_synth_hashes(uint8_t *d_out, uint64_t first, uint64_t count, uint
                             uint64_t n_clusters, hipStream_t stream);
 
 int rph_launch_read_stream(const void *d_buf, size_t bytes, uint32_t *d_sink, hipStream_t stream);
+
+// Runs an entry point's body; no C++ exception crosses the C ABI ("nothing aborts", include/rupphash.h)
+template <class F>
+static inline int rph_guarded(const char *where, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        rph_set_error("%s: out of host memory", where);
+        return RPH_ERR_OOM;
+    } catch (const std::exception &e) {
+        rph_set_error("%s: %s", where, e.what());
+        return RPH_ERR_HIP;
+    } catch (...) {
+        rph_set_error("%s: unknown exception", where);
+        return RPH_ERR_HIP;
+    }
+}
 
 // batcher.cpp
 void rph_batcher_forget(rph_ctx *ctx);
