@@ -56,7 +56,29 @@ __device__ __forceinline__ void box_one_d(const float *__restrict__ in, float *_
         ri += stride;
         oi += stride;
     }
-    for (uint32_t t = 0; t < phase_3; t++) {
+    // The bulk of the line.  The loads do not depend on the running sum, so they are issued eight steps ahead of the
+    // (strictly sequential) arithmetic; the order of the additions and of the division is the reference's.
+    uint32_t t = 0;
+    for (; t + 8 <= phase_3; t += 8) {
+        float r[8], l[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            r[k] = in[ri + k * stride];
+            l[k] = in[li + k * stride];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            sum = sum + r[k];
+            sum = sum - l[k];
+            o[k] = sum / cur;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) out[oi + k * stride] = o[k];
+        li += 8 * stride;
+        ri += 8 * stride;
+        oi += 8 * stride;
+    }
+    for (; t < phase_3; t++) {
         sum = sum + in[ri];
         sum = sum - in[li];
         out[oi] = sum / cur;
