@@ -317,23 +317,31 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
                 const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * PW * 16;
 #pragma unroll
                 for (int kb = 0; kb < PW; kb++) B[kb] = *reinterpret_cast<const v4i *>(bp + kb * 16);
-                auto screen = [&](const v16i &acc, int rb) {
-                    // max of the 16 accumulators as a tree of v_max3_i32 (depth 3): a linear chain of dependent VALU instructions
-                    // issues at ~9 clk each from one wave (tools/valu_dep.hip), independent ones at ~5.6
+                auto push = [&](const v16i &acc, int rb) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        if (acc[r] >= thresh_dot) {
+                            // C/D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                            const uint32_t row_in_tile = wrow + 32u * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const uint32_t col_in_chunk = cb * 32 + c32;
+                            const uint32_t at = atomicAdd(&s_qn[wave], 1u);
+                            if (at < QCAP) s_q[wave][at] = (row_in_tile << 16) | col_in_chunk;
+                        }
+                    }
+                };
+                // max of the 16 accumulators as a tree of v_max3_i32 (depth 3): a linear chain of dependent VALU instructions
+                // issues at ~9 clk each from one wave (tools/valu_dep.hip), independent ones at ~5.6
+                auto max16 = [&](const v16i &acc) {
                     const int m0 = max3i(acc[0], acc[1], acc[2]), m1 = max3i(acc[3], acc[4], acc[5]), m2 = max3i(acc[6], acc[7], acc[8]);
                     const int m3 = max3i(acc[9], acc[10], acc[11]), m4 = max3i(acc[12], acc[13], acc[14]);
-                    const int m = max3i(max3i(m0, m1, m2), max3i(m3, m4, acc[15]), m0);
-                    if (m >= thresh_dot) {  // rare
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            if (acc[r] >= thresh_dot) {
-                                // C/D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-                                const uint32_t row_in_tile = wrow + 32u * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                const uint32_t col_in_chunk = cb * 32 + c32;
-                                const uint32_t at = atomicAdd(&s_qn[wave], 1u);
-                                if (at < QCAP) s_q[wave][at] = (row_in_tile << 16) | col_in_chunk;
-                            }
-                        }
+                    return max3i(max3i(m0, m1, m2), max3i(m3, m4, acc[15]), m0);
+                };
+                // one test and one branch for the two tiles of a chain pair
+                auto screen2 = [&](const v16i &a0, const v16i &a1, int rb) {
+                    const int ma = max16(a0), mb = max16(a1);
+                    if ((ma > mb ? ma : mb) >= thresh_dot) {  // rare
+                        push(a0, rb);
+                        push(a1, rb + 1);
                     }
                 };
                 // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
@@ -347,8 +355,7 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
                         acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[rb][kb], B[kb], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[rb + 1][kb], B[kb], acc1, 0, 0, 0);
                     }
-                    screen(acc0, rb);
-                    screen(acc1, rb + 1);
+                    screen2(acc0, acc1, rb);
                 }
             }
 
