@@ -209,9 +209,7 @@ def main():
         dist.all_reduce(t)
         n_edges = int(t.item())
     expected_edges = n_clusters * 10 + (1 if n_h >= 10 else 0)
-    pw = 4 if args.threshold <= 36 else 5 if args.threshold <= 48 else 6 if args.threshold <= 60 else 7 if args.threshold <= 74 else 8
-    if args.hamming_kernel == 2:
-        pw = 4 if args.threshold <= 36 else 6 if args.threshold <= 60 else 8
+    pw = eng.L.rph_hamming_prefix_dwords(args.threshold, args.hamming_kernel)  # prefix dwords the fast path examines
     pairs_per_s_rank = (n_pairs / world) / (h_kernel_ms * 1e-3)
     if args.hamming_kernel == 2:
         # fp4 MFMA fast path (experiment, slower than int8 here): same 64 * PW ops per pair against the ~10 PFLOP/s dense fp4 peak

@@ -137,6 +137,9 @@ uint16_t rph_get_chunk64(uint64_t h, uint32_t chunk_idx);
  * 2 = fp4 MFMA (experiment; measured slower than int8).  All feed the same exact completion and report identical
  * edges.  Debug/bench. */
 int rph_hamming_set_kernel(rph_ctx *ctx, int which);
+/* Width (in 32-bit words, 4..8) of the hash prefix the sweep's fast path examines for `threshold` under formulation `kernel`
+ * (as in rph_hamming_set_kernel).  Informational (bench.py prices the fast path with it): results never depend on it. */
+int rph_hamming_prefix_dwords(uint32_t threshold, int kernel);
 
 /* One reported pair of the all-pairs sweep. */
 typedef struct rph_edge {

@@ -56,6 +56,7 @@ SIGNATURES = {
     "rph_pdq_hashes_from_coeffs_dev": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp]),
     "rph_pdq_set_kernel": (C.c_int, [_vp, C.c_int]),
     "rph_hamming_set_kernel": (C.c_int, [_vp, C.c_int]),
+    "rph_hamming_prefix_dwords": (C.c_int, [C.c_uint32, C.c_int]),
     "rph_pdq_target_dimensions": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rph_hamming_distance256": (C.c_uint32, [_u8p, _u8p]),
     "rph_hamming_distance64": (C.c_uint32, [C.c_uint64, C.c_uint64]),

@@ -53,6 +53,7 @@ struct SweepArgs {
     uint32_t part, nparts;
     unsigned long long n_tile_pairs;
     unsigned long long block0;  // first tile-pair slot of this launch (a launch carries at most MAX_GRID blocks)
+    uint32_t seg_tiles;         // int8 MFMA kernel: column tiles per block (a block sweeps one row tile against a segment of column tiles)
     uint32_t n_tiles;
     rph_edge *edges;
     unsigned long long cap;
@@ -74,6 +75,30 @@ __device__ __forceinline__ void tile_pair(unsigned long long p, uint32_t nt, uin
     while (i + 1 < (long long)nt && off(i + 1) <= p) ++i;
     I = (uint32_t)i;
     J = (uint32_t)(i + (long long)(p - off(i)));
+}
+
+// Segment enumeration of the int8 MFMA kernel: row tile I is swept against segments of S consecutive column tiles
+// [J0, J0 + S), J0 = I, I + S, ... ; blocks are numbered row-major in I.  G(M) = sum_{m=1..M} ceil(m / S) blocks cover the
+// last M row tiles, so f(I) = G(nt) - G(nt - I) blocks precede row tile I.  (Python mirror: rupphash_amd/dist.py.)
+__host__ __device__ __forceinline__ unsigned long long seg_G(unsigned long long M, unsigned long long S)
+{
+    const unsigned long long q = M / S, r = M % S;
+    return S * q * (q + 1) / 2 + (q + 1) * r;
+}
+__device__ __forceinline__ void seg_block(unsigned long long b, uint32_t nt, uint32_t S, uint32_t &I, uint32_t &J0)
+{
+    const unsigned long long total = seg_G(nt, S);
+    auto f = [&](long long ii) { return total - seg_G((unsigned long long)(nt - ii), S); };
+    const double N = (double)nt + 0.5 * (double)S;
+    double disc = N * N - 2.0 * (double)S * (double)b;
+    disc = disc > 0.0 ? disc : 0.0;
+    long long i = (long long)(N - sqrt(disc));
+    if (i < 0) i = 0;
+    if (i >= (long long)nt) i = nt - 1;
+    while (i > 0 && f(i) > b) --i;
+    while (i + 1 < (long long)nt && f(i + 1) <= b) ++i;
+    I = (uint32_t)i;
+    J0 = (uint32_t)(i + (long long)(b - f(i)) * S);
 }
 
 // Slow path for one (row, column) pair whose partial distance passed: exact distance,
@@ -222,21 +247,24 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
 {
     constexpr int PITCH = 2 * PW * 16 + 16;  // bytes per column: [k-half h][dword kb][16 x i8] + pad (conflict-free b128, lane = column)
     constexpr int CHUNK = PW <= 4 ? 256 : 128;  // columns expanded into LDS at a time (two buffers)
-    constexpr int QCAP = 256;                // candidate queue per wave and chunk; overflow falls back to an exhaustive completion
+    constexpr int QCAP = 128;                // candidate queue per wave (entries of 8 bytes); overflow falls back to an exhaustive completion
     constexpr int MF_RB = PW <= 4 ? 8 : 4;   // 32-row blocks per wave and pass (A fragments: MF_RB * PW * 4 VGPRs)
     constexpr int PASS_ROWS = 4 * 32 * MF_RB; // rows one pass of the 4 waves covers; T_FILES / PASS_ROWS passes per tile
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * CHUNK * PITCH];
     __shared__ uint2 s_lut[256];
-    __shared__ uint32_t s_q[4][QCAP];   // one queue per wave: filled and drained by the same wave, no barrier needed
+    __shared__ uint2 s_q[4][QCAP];      // one queue per wave: filled and drained by the same wave, no barrier needed
     __shared__ uint32_t s_qn[4];
 
+    // one block = row tile I against the column tiles [J0, J0 + seg_tiles): the row fragments are built once, and the wait for
+    // the (rare) candidates' exact completion is paid once per segment instead of once per tile
     const unsigned long long p = (unsigned long long)a.part + (a.block0 + blockIdx.x) * a.nparts;
-    if (p >= a.n_tile_pairs) return;
+    if (p >= a.n_tile_pairs) return;  // (for this kernel: the number of segment blocks)
     uint32_t I, J;
-    tile_pair(p, a.n_tiles, I, J);
+    seg_block(p, a.n_tiles, a.seg_tiles, I, J);
     const unsigned long long col0 = (unsigned long long)J * T_FILES;
     const unsigned long long row0 = (unsigned long long)I * T_FILES;
-    const uint32_t ncols = (uint32_t)((a.n - col0) < (unsigned long long)T_FILES ? (a.n - col0) : T_FILES);
+    const unsigned long long seg_cols = (unsigned long long)a.seg_tiles * T_FILES;
+    const uint32_t ncols = (uint32_t)((a.n - col0) < seg_cols ? (a.n - col0) : seg_cols);  // <= 8192: queue entries keep 16 bits for it
 
     s_lut[threadIdx.x] = expand_byte(threadIdx.x);
     if (threadIdx.x < 4) s_qn[threadIdx.x] = 0;
@@ -302,6 +330,7 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
         };
         fetch(0);
         int which = 0;
+        uint32_t undrained = 0;
         for (uint32_t cbase = 0; cbase < ncols; cbase += CHUNK, which ^= 1) {
             uint8_t *s_b = s_buf + which * (CHUNK * PITCH);
             expand(cbase, s_b);
@@ -310,6 +339,7 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
 
             // ---- fast path: MFMA + VALU screen only.  No global memory operation lives in this loop (candidates go to
             // an LDS queue), so the compiler never has to drain vmcnt here and the prefetch above stays in flight.
+            uint32_t cand = 0;  // bit (cb * MF_RB / 2 + rb / 2): this lane saw a candidate among its 32 pairs of column block cb, row blocks rb, rb + 1
 #pragma unroll 1
             for (int cb = 0; cb < CHUNK / 32; cb++) {
                 if (cbase + cb * 32 >= ncols) break;
@@ -317,18 +347,6 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
                 const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * PW * 16;
 #pragma unroll
                 for (int kb = 0; kb < PW; kb++) B[kb] = *reinterpret_cast<const v4i *>(bp + kb * 16);
-                auto push = [&](const v16i &acc, int rb) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        if (acc[r] >= thresh_dot) {
-                            // C/D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-                            const uint32_t row_in_tile = wrow + 32u * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            const uint32_t col_in_chunk = cb * 32 + c32;
-                            const uint32_t at = atomicAdd(&s_qn[wave], 1u);
-                            if (at < QCAP) s_q[wave][at] = (row_in_tile << 16) | col_in_chunk;
-                        }
-                    }
-                };
                 // max of the 16 accumulators as a tree of v_max3_i32 (depth 3): a linear chain of dependent VALU instructions
                 // issues at ~9 clk each from one wave (tools/valu_dep.hip), independent ones at ~5.6
                 auto max16 = [&](const v16i &acc) {
@@ -336,13 +354,12 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
                     const int m3 = max3i(acc[9], acc[10], acc[11]), m4 = max3i(acc[12], acc[13], acc[14]);
                     return max3i(max3i(m0, m1, m2), max3i(m3, m4, acc[15]), m0);
                 };
-                // one test and one branch for the two tiles of a chain pair
+                // One test for the two tiles of a chain pair, and no branch: the lane only sets bit (cb, rb / 2) of its candidate
+                // bitmap of the chunk.  (A branch here, however rare, stalls this wave's MFMA issue and, through the chunk
+                // barriers, its three block mates: 8e6 queue pushes cost 10 ms at threshold 40.)
                 auto screen2 = [&](const v16i &a0, const v16i &a1, int rb) {
                     const int ma = max16(a0), mb = max16(a1);
-                    if ((ma > mb ? ma : mb) >= thresh_dot) {  // rare
-                        push(a0, rb);
-                        push(a1, rb + 1);
-                    }
+                    cand |= ((ma > mb ? ma : mb) >= thresh_dot) ? (1u << (cb * (MF_RB / 2) + rb / 2)) : 0u;
                 };
                 // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
                 // independent one every 32: tools/mfma_rate.hip)
@@ -359,27 +376,56 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
                 }
             }
 
-            // ---- complete this wave's candidates of the chunk exactly (outside the MFMA loop; wave-local, the LDS
-            // executes one wave's operations in order, so no barrier is needed between push, read and reset)
+            // ---- lanes with candidates append (bitmap, column) to the wave's queue: slots by ballot rank, no atomics
+            // (wave-local: the LDS executes one wave's operations in order, so no barrier is needed between push, read and reset)
             asm volatile("" ::: "memory");
-            const uint32_t nq = s_qn[wave];
-            if (nq != 0) {
+            const unsigned long long vote = __builtin_amdgcn_ballot_w64(cand != 0);
+            uint32_t nq = s_qn[wave];
+            if (vote != 0) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
+                const uint32_t slot = nq + rank;
+                if (cand != 0 && slot < QCAP) s_q[wave][slot] = make_uint2(cand, ((uint32_t)h << 16) | (cbase + c32));
+                nq += (uint32_t)__builtin_popcountll(vote);
+                if (lane == 0) s_qn[wave] = nq;
+                asm volatile("" ::: "memory");
+            }
+            // ---- complete the queued candidates exactly.  A drain costs a global-memory round trip whatever it holds, so it waits
+            // until a full wave of entries is queued or the pass ends; `undrained` is the first column of the segment whose
+            // candidates may still sit in the queue.
+            const uint32_t cend = (cbase + CHUNK) < ncols ? (cbase + CHUNK) : ncols;
+            if (nq == 0) {
+                undrained = cend;
+            } else if (nq >= 64 || cend == ncols) {
                 if (nq <= QCAP) {
                     for (uint32_t t = lane; t < nq; t += 64) {
-                        const uint32_t e = s_q[wave][t];
-                        const unsigned long long owner = row0 + (e >> 16), col = col0 + cbase + (e & 0xFFFFu);
-                        if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                        const uint2 e = s_q[wave][t];
+                        const uint32_t eh = e.y >> 16;
+                        uint32_t bm = e.x;
+                        while (bm != 0) {
+                            const uint32_t bit = (uint32_t)__builtin_ctz(bm);
+                            bm &= bm - 1;
+                            const uint32_t rb = 2u * (bit % (MF_RB / 2));
+                            const unsigned long long col = col0 + (e.y & 0xFFFFu) + 32u * (bit / (MF_RB / 2));
+                            // the 32 pairs of that lane: C/D layout of the two tiles: row = (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll 1
+                            for (uint32_t r = 0; r < 32; r++) {
+                                const unsigned long long owner = row0 + wrow + 32u * (rb + (r >> 4)) + (r & 3u) + 8u * ((r >> 2) & 3u) + 4u * eh;
+                                if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                            }
+                        }
                     }
                 } else {
-                    // queue overflow (heavily duplicated data): every pair of this wave's rows and this chunk is completed exactly
-                    const uint32_t ccols = (ncols - cbase) < (uint32_t)CHUNK ? (ncols - cbase) : (uint32_t)CHUNK;
+                    // queue overflow (heavily duplicated data): every pair of this wave's rows and the columns since the last
+                    // drain is completed exactly
+                    const uint32_t ccols = cend - undrained;
                     for (uint32_t t = lane; t < (uint32_t)(32 * MF_RB) * ccols; t += 64) {
-                        const unsigned long long owner = row0 + wrow + t / ccols, col = col0 + cbase + t % ccols;
+                        const unsigned long long owner = row0 + wrow + t / ccols, col = col0 + undrained + t % ccols;
                         if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
                     }
                 }
                 asm volatile("" ::: "memory");
                 if (lane == 0) s_qn[wave] = 0;
+                undrained = cend;
             }
         }
         __syncthreads();  // the last chunk's buffers and queue are free before the next pass starts
@@ -626,6 +672,25 @@ __global__ void __launch_bounds__(256) hamming64_sweep_kernel(Sweep64Args a)
 
 }  // namespace
 
+// Prefix width of the fast path, in dwords.  The partial distance over the first 32 PW bits is a lower bound of the distance, so
+// the fast path only has to keep unrelated pairs away from the exact completion: for unrelated hashes it is ~ N(16 PW, 8 PW).
+// The smallest PW that leaves >= 4.2 sigma to the threshold lets fewer than ~1.3e-5 of the pairs through (<= 7 M exact
+// completions per 5e11 pairs, well under a millisecond); correctness never depends on it (the completion is exact, and a
+// flooded candidate queue falls back to exhaustive completion).  kernel 2 (fp4) works on 64-bit slices: PW even.
+extern "C" int rph_hamming_prefix_dwords(uint32_t threshold, int kernel)
+{
+    int pw = 8;
+    for (int cand = 4; cand < 8; cand++) {
+        const double mean = 16.0 * cand, sigma = sqrt(8.0 * cand);
+        if ((mean - (double)threshold) / sigma >= 4.2) {
+            pw = cand;
+            break;
+        }
+    }
+    if (kernel == 2 && (pw & 1)) pw++;
+    return pw;
+}
+
 int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
                              const uint8_t *d_has_features, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts, rph_edge *d_edges,
                              uint64_t cap, unsigned long long *d_count, hipStream_t stream, int use_mfma)
@@ -649,43 +714,50 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
     a.nparts = nparts;
     a.n_tiles = (uint32_t)((n + T_FILES - 1) / T_FILES);
     a.n_tile_pairs = (unsigned long long)a.n_tiles * (a.n_tiles + 1ull) / 2ull;
+    a.seg_tiles = 1;
+    if (use_mfma == 1) {
+        // int8 MFMA kernel: a block sweeps a row tile against a segment of up to 8 column tiles; shorter segments while that
+        // would leave this rank fewer than ~8 blocks per resident block slot (2 per CU)
+        const unsigned long long want_blocks = 8ull * 512ull * nparts;
+        unsigned long long S = a.n_tile_pairs / want_blocks;
+        a.seg_tiles = (uint32_t)(S < 1 ? 1 : (S > 8 ? 8 : S));
+        a.n_tile_pairs = seg_G(a.n_tiles, a.seg_tiles);  // number of segment blocks
+    }
     a.edges = d_edges;
     a.cap = cap;
     a.count = d_count;
     const unsigned long long mine = (a.n_tile_pairs > part) ? (a.n_tile_pairs - part + nparts - 1) / nparts : 0;
     if (mine == 0) return RPH_OK;
-    // Partial-width test: unrelated 256-bit hashes differ in ~16*PW +- sqrt(8*PW) of the first
-    // 32*PW bits; keep ~5 sigma between that and the threshold.
-    const uint32_t t = a.threshold;
+    const int pw = rph_hamming_prefix_dwords(a.threshold, use_mfma);
     for (unsigned long long b0 = 0; b0 < mine; b0 += MAX_GRID) {  // one launch carries at most MAX_GRID tile pairs
         a.block0 = b0;
         const dim3 grid((unsigned)((mine - b0) < MAX_GRID ? (mine - b0) : MAX_GRID)), block(BLOCK), mblock(MF_BLOCK);
         if (use_mfma == 2) {
-            if (t <= 36)
+            if (pw == 4)
                 hipLaunchKernelGGL(hamming_fp4_kernel<4>, grid, mblock, 0, stream, a);
-            else if (t <= 60)
+            else if (pw == 6)
                 hipLaunchKernelGGL(hamming_fp4_kernel<6>, grid, mblock, 0, stream, a);
             else
                 hipLaunchKernelGGL(hamming_fp4_kernel<8>, grid, mblock, 0, stream, a);
         } else if (use_mfma) {
-            if (t <= 36)
+            if (pw == 4)
                 hipLaunchKernelGGL(hamming_mfma_kernel<4>, grid, mblock, 0, stream, a);
-            else if (t <= 48)
+            else if (pw == 5)
                 hipLaunchKernelGGL(hamming_mfma_kernel<5>, grid, mblock, 0, stream, a);
-            else if (t <= 60)
+            else if (pw == 6)
                 hipLaunchKernelGGL(hamming_mfma_kernel<6>, grid, mblock, 0, stream, a);
-            else if (t <= 74)
+            else if (pw == 7)
                 hipLaunchKernelGGL(hamming_mfma_kernel<7>, grid, mblock, 0, stream, a);
             else
                 hipLaunchKernelGGL(hamming_mfma_kernel<8>, grid, mblock, 0, stream, a);
         } else {
-            if (t <= 36)
+            if (pw == 4)
                 hipLaunchKernelGGL(hamming_sweep_kernel<4>, grid, block, 0, stream, a);
-            else if (t <= 48)
+            else if (pw == 5)
                 hipLaunchKernelGGL(hamming_sweep_kernel<5>, grid, block, 0, stream, a);
-            else if (t <= 60)
+            else if (pw == 6)
                 hipLaunchKernelGGL(hamming_sweep_kernel<6>, grid, block, 0, stream, a);
-            else if (t <= 74)
+            else if (pw == 7)
                 hipLaunchKernelGGL(hamming_sweep_kernel<7>, grid, block, 0, stream, a);
             else
                 hipLaunchKernelGGL(hamming_sweep_kernel<8>, grid, block, 0, stream, a);

@@ -51,6 +51,36 @@ def tile_pairs_of_part(n, part, nparts, tile=TILE):
     return [tile_pair(p, nt) for p in range(part, n_tile_pairs(n, tile), nparts)]
 
 
+def seg_g(m, s):
+    """blocks that cover the last m row tiles when a row tile is cut into segments of s column tiles"""
+    q, r = divmod(m, s)
+    return s * q * (q + 1) // 2 + (q + 1) * r
+
+
+def seg_block(b, nt, s):
+    """block index -> (I, J0): the enumeration of hamming_kernels.hip::seg_block (int8 MFMA kernel): row tile I against the
+    column tiles [J0, min(J0 + s, nt)), J0 = I, I + s, ...; row-major in I"""
+    total = seg_g(nt, s)
+
+    def f(ii):
+        return total - seg_g(nt - ii, s)
+
+    big = nt + 0.5 * s
+    i = int(big - max(big * big - 2.0 * s * b, 0.0) ** 0.5)
+    i = max(0, min(i, nt - 1))
+    while i > 0 and f(i) > b:
+        i -= 1
+    while i + 1 < nt and f(i + 1) <= b:
+        i += 1
+    return i, i + (b - f(i)) * s
+
+
+def seg_blocks_of_part(n, part, nparts, s, tile=TILE):
+    """the (I, J0) segment blocks rank `part` of `nparts` sweeps (round robin over the block index)"""
+    nt = (n + tile - 1) // tile
+    return [seg_block(b, nt, s) for b in range(part, seg_g(nt, s), nparts)]
+
+
 def all_gather_hashes(local_hashes, n_total, dist=None, device_tensor=False):
     """One all-gather of the per-rank hash shards into the full (n_total, 32) array on every rank.
 

@@ -37,6 +37,20 @@ def test_tile_pairs_partition_is_exact(n, tile, nparts):
     assert set(seen) == {(i, j) for i in range(nt) for j in range(i, nt)}
 
 
+@pytest.mark.parametrize("n,tile,nparts,s", [(1, 4, 1, 8), (10, 4, 3, 2), (5000, 64, 3, 8), (4096, 1024, 8, 1), (777, 64, 5, 3), (70000, 64, 4, 8)])
+def test_segment_blocks_partition_is_exact(n, tile, nparts, s):
+    """the int8 MFMA kernel's enumeration: every (row tile, column tile >= row tile) pair lies in exactly one segment block"""
+    from rupphash_amd import dist as D
+
+    nt = (n + tile - 1) // tile
+    covered = []
+    for part in range(nparts):
+        for (i, j0) in D.seg_blocks_of_part(n, part, nparts, s, tile):
+            assert 0 <= i <= j0 < nt and (j0 - i) % s == 0
+            covered += [(i, j) for j in range(j0, min(j0 + s, nt))]
+    assert len(covered) == nt * (nt + 1) // 2 and set(covered) == {(i, j) for i in range(nt) for j in range(i, nt)}
+
+
 def test_shard_ranges_cover():
     from rupphash_amd import dist as D
 
