@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--threshold", type=int, default=32)
     ap.add_argument("--hamming-steps", type=int, default=0, help="default: same as --steps")
     ap.add_argument("--pdq-kernel", type=int, default=1, help="1 = fused, 64-px strips (default), 2 = fused, 128-px strips, 0 = generic multi-pass")
-    ap.add_argument("--hamming-kernel", type=int, default=1, help="1 = int8 MFMA fast path (default), 2 = fp4 MFMA fast path, 0 = VALU xor + popcount")
+    ap.add_argument("--hamming-kernel", type=int, default=2, help="2 = fp4 MFMA fast path (default), 1 = int8 MFMA fast path, 0 = VALU xor + popcount")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal: ranks may "
                     "share one GPU, collectives are staged through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -212,9 +212,10 @@ def main():
     pw = eng.L.rph_hamming_prefix_dwords(args.threshold, args.hamming_kernel)  # prefix dwords the fast path examines
     pairs_per_s_rank = (n_pairs / world) / (h_kernel_ms * 1e-3)
     if args.hamming_kernel == 2:
-        # fp4 MFMA fast path (experiment, slower than int8 here): same 64 * PW ops per pair against the ~10 PFLOP/s dense fp4 peak
-        h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": 10066.0, "unit": "TOP/s (fp4)",
-                  "frac": pairs_per_s_rank * 64 * pw / 10066e12, "prefix_dwords": pw, "hbm_bytes_per_pair": 64.0 / 1024,
+        # fp4 MFMA fast path: one v_mfma_scale_f32_32x32x64_f8f6f4 (131 072 fp4 ops) per 64-bit slice of 1024 pairs -> 64 * PW ops per pair,
+        # against the dense fp4 peak (2 x the fp8 / int8 peak)
+        h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": 2 * MFMA_I8_OPS_PER_S / 1e12, "unit": "TOP/s (fp4)",
+                  "frac": pairs_per_s_rank * 64 * pw / (2 * MFMA_I8_OPS_PER_S), "int8_equivalent_ops_per_pair": 64 * pw, "prefix_dwords": pw, "hbm_bytes_per_pair": 64.0 / 1024,
                   "kernel_ms": h_kernel_ms, "kernel": "hamming_fp4_kernel"}
     elif args.hamming_kernel == 1:
         # int8 MFMA fast path: one v_mfma_i32_32x32x32_i8 (65 536 int8 ops) per 32-bit slice of 1024 pairs -> 64 * PW ops per pair

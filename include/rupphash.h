@@ -133,9 +133,8 @@ uint32_t rph_hamming_distance64(uint64_t a, uint64_t b);
 uint16_t rph_get_chunk256(const uint8_t *h32, uint32_t chunk_idx);
 uint16_t rph_get_chunk64(uint64_t h, uint32_t chunk_idx);
 
-/* Which formulation the sweep's fast path uses: 1 = int8 MFMA (+-1 encoded bits, default), 0 = VALU xor + popcount,
- * 2 = fp4 MFMA (experiment; measured slower than int8).  All feed the same exact completion and report identical
- * edges.  Debug/bench. */
+/* Which formulation the sweep's fast path uses: 2 = fp4 MFMA (+-1 encoded bits as e2m1, default), 1 = int8 MFMA,
+ * 0 = VALU xor + popcount.  All feed the same exact completion and report identical edges.  Debug/bench. */
 int rph_hamming_set_kernel(rph_ctx *ctx, int which);
 /* Width (in 32-bit words, 4..8) of the hash prefix the sweep's fast path examines for `threshold` under formulation `kernel`
  * (as in rph_hamming_set_kernel).  Informational (bench.py prices the fast path with it): results never depend on it. */

@@ -433,29 +433,34 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
 }
 
 
-// FP4 (e2m1) formulation: +1 = 0x2, -1 = 0xA, one v_mfma_scale_f32_32x32x64_f8f6f4 (scales 1.0) evaluates a 64-bit slice
-// of 32 x 32 pairs; f32 accumulation of +-1 products is exact.  PW (even) = prefix dwords.
+// FP4 (e2m1) formulation, same structure as the int8 kernel: +1 = 0x2, -1 = 0xA, one v_mfma_scale_f32_32x32x64_f8f6f4 (scales 1.0)
+// evaluates a 64-bit slice of 32 x 32 pairs; f32 accumulation of +-1 products is exact.  PW (even) = prefix dwords.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
 template <int PW>
 __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_fp4_kernel(SweepArgs a)
 {
-    constexpr int NK = PW / 2;                // MFMAs (64-bit slices) per tile
+    constexpr int NK = PW / 2;               // MFMAs (64-bit slices) per tile
     constexpr int PITCH = PW * 16 + 16;      // bytes per column: [k-half h][slice][32 x fp4 = 16 B] + pad
-    constexpr int CHUNK = 256;  // columns expanded into LDS at a time (two buffers)
-    constexpr int QCAP = 256;                // candidate queue per wave and chunk; overflow falls back to an exhaustive completion
-    constexpr int MF_RB = 8;   // 32-row blocks per wave and pass (A fragments: MF_RB * PW * 4 VGPRs)
+    constexpr int CHUNK = 256;               // columns expanded into LDS at a time (two buffers)
+    constexpr int QCAP = 128;                // candidate queue per wave (entries of 8 bytes); overflow falls back to an exhaustive completion
+    constexpr int MF_RB = 8;                 // 32-row blocks per wave and pass (A fragments: MF_RB * NK * 4 VGPRs)
     constexpr int PASS_ROWS = 4 * 32 * MF_RB; // rows one pass of the 4 waves covers; T_FILES / PASS_ROWS passes per tile
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * CHUNK * PITCH];
     __shared__ uint32_t s_lut[256];     // byte -> 8 fp4 codes
-    __shared__ uint32_t s_q[4][QCAP];   // one queue per wave: filled and drained by the same wave, no barrier needed
+    __shared__ uint2 s_q[4][QCAP];      // one queue per wave: filled and drained by the same wave, no barrier needed
     __shared__ uint32_t s_qn[4];
 
+    // one block = row tile I against the column tiles [J0, J0 + seg_tiles): the row fragments are built once, and the wait for
+    // the (rare) candidates' exact completion is paid once per segment instead of once per tile
     const unsigned long long p = (unsigned long long)a.part + (a.block0 + blockIdx.x) * a.nparts;
-    if (p >= a.n_tile_pairs) return;
+    if (p >= a.n_tile_pairs) return;  // (for this kernel: the number of segment blocks)
     uint32_t I, J;
-    tile_pair(p, a.n_tiles, I, J);
+    seg_block(p, a.n_tiles, a.seg_tiles, I, J);
     const unsigned long long col0 = (unsigned long long)J * T_FILES;
     const unsigned long long row0 = (unsigned long long)I * T_FILES;
-    const uint32_t ncols = (uint32_t)((a.n - col0) < (unsigned long long)T_FILES ? (a.n - col0) : T_FILES);
+    const unsigned long long seg_cols = (unsigned long long)a.seg_tiles * T_FILES;
+    const uint32_t ncols = (uint32_t)((a.n - col0) < seg_cols ? (a.n - col0) : seg_cols);  // <= 8192: queue entries keep 16 bits for it
 
     {
         uint32_t e = 0;
@@ -522,6 +527,7 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_fp4_kernel(SweepArgs a)
         };
         fetch(0);
         int which = 0;
+        uint32_t undrained = 0;
         for (uint32_t cbase = 0; cbase < ncols; cbase += CHUNK, which ^= 1) {
             uint8_t *s_b = s_buf + which * (CHUNK * PITCH);
             expand(cbase, s_b);
@@ -530,6 +536,7 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_fp4_kernel(SweepArgs a)
 
             // ---- fast path: MFMA + VALU screen only.  No global memory operation lives in this loop (candidates go to
             // an LDS queue), so the compiler never has to drain vmcnt here and the prefetch above stays in flight.
+            uint32_t cand = 0;  // bit (cb * MF_RB / 2 + rb / 2): this lane saw a candidate among its 32 pairs of column block cb, row blocks rb, rb + 1
 #pragma unroll 1
             for (int cb = 0; cb < CHUNK / 32; cb++) {
                 if (cbase + cb * 32 >= ncols) break;
@@ -540,22 +547,19 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_fp4_kernel(SweepArgs a)
                     const v4i t = *reinterpret_cast<const v4i *>(bp + ks * 16);
                     B[ks] = v8i{t[0], t[1], t[2], t[3], 0, 0, 0, 0};
                 }
-                auto screen = [&](const v16f &acc, int rb) {
-                    float m = acc[0];
-#pragma unroll
-                    for (int r = 1; r < 16; r++) m = acc[r] > m ? acc[r] : m;
-                    if (m >= thresh_dot) {  // rare
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            if (acc[r] >= thresh_dot) {
-                                // C/D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-                                const uint32_t row_in_tile = wrow + 32u * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                const uint32_t col_in_chunk = cb * 32 + c32;
-                                const uint32_t at = atomicAdd(&s_qn[wave], 1u);
-                                if (at < QCAP) s_q[wave][at] = (row_in_tile << 16) | col_in_chunk;
-                            }
-                        }
-                    }
+                // max of the 16 accumulators as a tree of v_max3_f32 (depth 3; exact integers, no NaNs): a linear chain of dependent VALU instructions
+                // issues at ~9 clk each from one wave (tools/valu_dep.hip), independent ones at ~5.6
+                auto max16 = [&](const v16f &acc) {
+                    const float m0 = max3f(acc[0], acc[1], acc[2]), m1 = max3f(acc[3], acc[4], acc[5]), m2 = max3f(acc[6], acc[7], acc[8]);
+                    const float m3 = max3f(acc[9], acc[10], acc[11]), m4 = max3f(acc[12], acc[13], acc[14]);
+                    return max3f(max3f(m0, m1, m2), max3f(m3, m4, acc[15]), m0);
+                };
+                // One test for the two tiles of a chain pair, and no branch: the lane only sets bit (cb, rb / 2) of its candidate
+                // bitmap of the chunk.  (A branch here, however rare, stalls this wave's MFMA issue and, through the chunk
+                // barriers, its three block mates: 8e6 queue pushes cost 10 ms at threshold 40.)
+                auto screen2 = [&](const v16f &a0, const v16f &a1, int rb) {
+                    const float ma = max16(a0), mb = max16(a1);
+                    cand |= ((ma > mb ? ma : mb) >= thresh_dot) ? (1u << (cb * (MF_RB / 2) + rb / 2)) : 0u;
                 };
                 // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
                 // independent one every 32: tools/mfma_rate.hip)
@@ -568,37 +572,67 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_fp4_kernel(SweepArgs a)
                         acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rb][ks], B[ks], acc0, 4, 4, 0, 127, 0, 127);
                         acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rb + 1][ks], B[ks], acc1, 4, 4, 0, 127, 0, 127);
                     }
-                    screen(acc0, rb);
-                    screen(acc1, rb + 1);
+                    screen2(acc0, acc1, rb);
                 }
             }
 
-            // ---- complete this wave's candidates of the chunk exactly (outside the MFMA loop; wave-local, the LDS
-            // executes one wave's operations in order, so no barrier is needed between push, read and reset)
+            // ---- lanes with candidates append (bitmap, column) to the wave's queue: slots by ballot rank, no atomics
+            // (wave-local: the LDS executes one wave's operations in order, so no barrier is needed between push, read and reset)
             asm volatile("" ::: "memory");
-            const uint32_t nq = s_qn[wave];
-            if (nq != 0) {
+            const unsigned long long vote = __builtin_amdgcn_ballot_w64(cand != 0);
+            uint32_t nq = s_qn[wave];
+            if (vote != 0) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
+                const uint32_t slot = nq + rank;
+                if (cand != 0 && slot < QCAP) s_q[wave][slot] = make_uint2(cand, ((uint32_t)h << 16) | (cbase + c32));
+                nq += (uint32_t)__builtin_popcountll(vote);
+                if (lane == 0) s_qn[wave] = nq;
+                asm volatile("" ::: "memory");
+            }
+            // ---- complete the queued candidates exactly.  A drain costs a global-memory round trip whatever it holds, so it waits
+            // until a full wave of entries is queued or the pass ends; `undrained` is the first column of the segment whose
+            // candidates may still sit in the queue.
+            const uint32_t cend = (cbase + CHUNK) < ncols ? (cbase + CHUNK) : ncols;
+            if (nq == 0) {
+                undrained = cend;
+            } else if (nq >= 64 || cend == ncols) {
                 if (nq <= QCAP) {
                     for (uint32_t t = lane; t < nq; t += 64) {
-                        const uint32_t e = s_q[wave][t];
-                        const unsigned long long owner = row0 + (e >> 16), col = col0 + cbase + (e & 0xFFFFu);
-                        if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                        const uint2 e = s_q[wave][t];
+                        const uint32_t eh = e.y >> 16;
+                        uint32_t bm = e.x;
+                        while (bm != 0) {
+                            const uint32_t bit = (uint32_t)__builtin_ctz(bm);
+                            bm &= bm - 1;
+                            const uint32_t rb = 2u * (bit % (MF_RB / 2));
+                            const unsigned long long col = col0 + (e.y & 0xFFFFu) + 32u * (bit / (MF_RB / 2));
+                            // the 32 pairs of that lane: C/D layout of the two tiles: row = (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll 1
+                            for (uint32_t r = 0; r < 32; r++) {
+                                const unsigned long long owner = row0 + wrow + 32u * (rb + (r >> 4)) + (r & 3u) + 8u * ((r >> 2) & 3u) + 4u * eh;
+                                if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                            }
+                        }
                     }
                 } else {
-                    // queue overflow (heavily duplicated data): every pair of this wave's rows and this chunk is completed exactly
-                    const uint32_t ccols = (ncols - cbase) < (uint32_t)CHUNK ? (ncols - cbase) : (uint32_t)CHUNK;
+                    // queue overflow (heavily duplicated data): every pair of this wave's rows and the columns since the last
+                    // drain is completed exactly
+                    const uint32_t ccols = cend - undrained;
                     for (uint32_t t = lane; t < (uint32_t)(32 * MF_RB) * ccols; t += 64) {
-                        const unsigned long long owner = row0 + wrow + t / ccols, col = col0 + cbase + t % ccols;
+                        const unsigned long long owner = row0 + wrow + t / ccols, col = col0 + undrained + t % ccols;
                         if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
                     }
                 }
                 asm volatile("" ::: "memory");
                 if (lane == 0) s_qn[wave] = 0;
+                undrained = cend;
             }
         }
         __syncthreads();  // the last chunk's buffers and queue are free before the next pass starts
     }
 }
+
+
 
 
 // ---------------------------------------------------------------------------------------------
@@ -715,8 +749,8 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
     a.n_tiles = (uint32_t)((n + T_FILES - 1) / T_FILES);
     a.n_tile_pairs = (unsigned long long)a.n_tiles * (a.n_tiles + 1ull) / 2ull;
     a.seg_tiles = 1;
-    if (use_mfma == 1) {
-        // int8 MFMA kernel: a block sweeps a row tile against a segment of up to 8 column tiles; shorter segments while that
+    if (use_mfma >= 1) {
+        // MFMA kernels: a block sweeps a row tile against a segment of up to 8 column tiles; shorter segments while that
         // would leave this rank fewer than ~8 blocks per resident block slot (2 per CU)
         const unsigned long long want_blocks = 8ull * 512ull * nparts;
         unsigned long long S = a.n_tile_pairs / want_blocks;

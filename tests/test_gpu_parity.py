@@ -193,20 +193,20 @@ def test_dihedral_hashes_match_physically_transformed_image(eng, oracle):
 
 
 # ------------------------------------------------------------------ Hamming sweep
-@pytest.mark.parametrize("kernel", [1, 0, 2])  # 1 = int8 MFMA fast path (default), 0 = VALU xor + popcount, 2 = fp4 MFMA
-@pytest.mark.parametrize("thr", [0, 10, 31, 32, 36, 37, 48, 49, 60, 61, 74, 75, 100, 200])
+@pytest.mark.parametrize("kernel", [2, 1, 0])  # 2 = fp4 MFMA fast path (default), 1 = int8 MFMA, 0 = VALU xor + popcount
+@pytest.mark.parametrize("thr", [0, 10, 31, 32, 36, 40, 41, 48, 53, 54, 60, 66, 67, 74, 80, 81, 100, 200])
 def test_all_pairs_matches_brute_force(eng, oracle, thr, kernel):
     rng = np.random.default_rng(300 + thr)
     hashes = clustered_hashes(rng, 2500, 60, min(thr + 20, 120))
     eng.set_hamming_kernel(kernel)
     got = eng.hamming_all_pairs(hashes, thr)
-    eng.set_hamming_kernel(1)
+    eng.set_hamming_kernel(2)
     want = oracle.all_pairs256(hashes, thr)
     assert edge_set(got) == sorted(map(tuple, want.tolist()))
     if thr == 32:  # flags (find_groups reachability / probe slot) agree between the two formulations
         eng.set_hamming_kernel(0 if kernel else 1)
         other = eng.hamming_all_pairs(hashes, thr)
-        eng.set_hamming_kernel(1)
+        eng.set_hamming_kernel(2)
         key = lambda e: sorted((int(x["i"]), int(x["j"]), int(x["d"]), int(x["flags"])) for x in e)
         assert key(got) == key(other)
 
@@ -333,7 +333,7 @@ def test_mih_build_matches_reference_csr(eng, oracle):
 
 
 # ------------------------------------------------------------------ full-size, construction-known answers
-@pytest.mark.parametrize("kernel,n", [(1, 1_000_000), (0, 1_000_000), (2, 1_000_000), (1, 3_100_000)])
+@pytest.mark.parametrize("kernel,n", [(2, 1_000_000), (1, 1_000_000), (0, 1_000_000), (2, 3_100_000), (1, 3_100_000)])
 def test_one_million_hashes_threshold_32(eng, oracle, kernel, n):
     """BASELINE config 3: 1M synthetic hashes, 1000 injected 5-member clusters + the distance-32 pair.
     The expected edge set follows from the construction (random 256-bit pairs at d <= 32 have
@@ -350,7 +350,7 @@ def test_one_million_hashes_threshold_32(eng, oracle, kernel, n):
         eng.set_hamming_kernel(kernel)
         eng.hamming_all_pairs_dev(d_h, n, 32, d_e, cap, d_c)
         eng.synchronize()
-        eng.set_hamming_kernel(1)
+        eng.set_hamming_kernel(2)
         cnt = np.zeros(1, np.uint64)
         eng.dev_download(cnt, d_c)
         from rupphash_amd import EDGE_DTYPE
