@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 template <int PW>
-__global__ void __launch_bounds__(MF_BLOCK, 2) hamming_fp4_kernel(SweepArgs a)
+__global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(SweepArgs a)
 {
     constexpr int NK = PW / 2;               // MFMAs (64-bit slices) per tile
     constexpr int PITCH = PW * 16 + 16;      // bytes per column: [k-half h][slice][32 x fp4 = 16 B] + pad
