@@ -640,3 +640,36 @@ def test_pdq_bad_strides_are_rejected(eng):
     assert b"" != eng.L.rph_last_error()
     # a single image needs no image_stride at all
     assert f(eng.ctx, img.ctypes.data, 1, 64, 64, 3, 192, 0, h32.ctypes.data, None, None, None, None) == _lib.RPH_OK
+
+
+def test_pdq_random_geometries_match_oracle(eng, oracle):
+    """40 random geometries (5..900 px a side, 1/3/4 channels, padded strides): generic kernel below 513 px, pre-downsample above"""
+    rng = np.random.default_rng(20261004)
+    from rupphash_amd._lib import check
+    for case in range(40):
+        w = int(rng.integers(5, 900))
+        h = int(rng.integers(5, 900))
+        if case % 8 == 0:
+            w = int(rng.choice([5, 6, 7, 63, 64, 65, 511, 512, 513]))
+        if case % 8 == 1:
+            h = int(rng.choice([5, 6, 7, 63, 64, 65, 511, 512, 513]))
+        ch = int(rng.choice([1, 3, 4]))
+        n = int(rng.integers(1, 4))
+        row_stride = w * ch + int(rng.integers(0, 9))
+        image_stride = row_stride * h + int(rng.integers(0, 33))
+        buf, imgs = _strided_batch(rng, n, h, w, ch, row_stride, image_stride)
+        # structure, so that hashes are not pure noise medians
+        hashes = np.zeros((n, 32), np.uint8)
+        quality = np.zeros(n, np.float32)
+        coeffs = np.zeros((n, 256), np.float32)
+        dihedral = np.zeros((n, 8, 32), np.uint8)
+        valid = np.zeros(n, np.uint8)
+        check(eng.L.rph_pdq_hash_batch(eng.ctx, buf.ctypes.data, n, w, h, ch, row_stride, image_stride, hashes.ctypes.data,
+                                       quality.ctypes.data, coeffs.ctypes.data, dihedral.ctypes.data, valid.ctypes.data), "rph_pdq_hash_batch")
+        for k in range(n):
+            rc, c, q = oracle.pdq_features(imgs[k])
+            assert rc == 0 and valid[k] == 1, (case, w, h, ch)
+            assert np.array_equal(bits(coeffs[k]), bits(c)), (case, w, h, ch, k)
+            assert bits(quality[k:k + 1])[0] == bits(np.float32(q))[()], (case, w, h, ch, k)
+            assert np.array_equal(hashes[k], oracle.to_hash(c)), (case, w, h, ch, k)
+            assert np.array_equal(dihedral[k], oracle.dihedral_hashes(c)), (case, w, h, ch, k)
