@@ -433,13 +433,42 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
 }
 
 
+// Exact completion of one u64 pair (impl HammingHash for u64, hamminghash.rs:23-41): distance, i < j, find_groups reachability
+// over 8 chunks of 8 bits (first chunk with popcount <= tol; slot 0 = exact bucket, 1 + b = flip of bit b), append.
+__device__ __forceinline__ void complete_pair_u64(const SweepArgs &a, unsigned long long owner, unsigned long long col)
+{
+    if (owner >= a.n || col >= a.n || col <= owner) return;  // i < j only (hamminghash.rs:216)
+    const uint2 rv = reinterpret_cast<const uint2 *>(a.rows)[owner], cv = reinterpret_cast<const uint2 *>(a.cols)[col];
+    const uint32_t x0 = rv.x ^ cv.x, x1 = rv.y ^ cv.y;
+    const uint32_t d = (uint32_t)__builtin_popcount(x0) + (uint32_t)__builtin_popcount(x1);
+    if (d > a.threshold) return;
+    uint32_t flags = 0;
+    for (int k = 7; k >= 0; k--) {
+        const uint32_t c8 = ((k < 4 ? x0 : x1) >> ((k & 3) * 8)) & 0xFFu;
+        const uint32_t pc = (uint32_t)__builtin_popcount(c8);
+        if (pc <= a.mih_tol) flags = RPH_EDGE_MIH_R1 | ((uint32_t)k << 5) | (pc == 0 ? 0u : 1u + (uint32_t)__builtin_ctz(c8));
+    }
+    const unsigned long long at = atomicAdd(a.count, 1ull);
+    if (at < a.cap) {
+        rph_edge e;
+        e.i = (uint32_t)owner;
+        e.j = (uint32_t)col;
+        e.d = (uint16_t)d;
+        e.flags = (uint16_t)flags;
+        a.edges[at] = e;
+    }
+}
+
 // FP4 (e2m1) formulation, same structure as the int8 kernel: +1 = 0x2, -1 = 0xA, one v_mfma_scale_f32_32x32x64_f8f6f4 (scales 1.0)
 // evaluates a 64-bit slice of 32 x 32 pairs; f32 accumulation of +-1 products is exact.  PW (even) = prefix dwords.
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-template <int PW>
+// U64: the hashes are 64-bit (stride 2 dwords, PW = 2: the whole hash is one MFMA slice) and pairs are completed by complete_pair_u64.
+template <int PW, bool U64 = false>
 __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(SweepArgs a)
 {
+    constexpr int HS = U64 ? 2 : 8;          // dwords per hash
+    static_assert(!U64 || PW == 2, "u64 hashes are swept at full width");
     constexpr int NK = PW / 2;               // MFMAs (64-bit slices) per tile
     constexpr int PITCH = PW * 16 + 16;      // bytes per column: [k-half h][slice][32 x fp4 = 16 B] + pad
     constexpr int CHUNK = 256;               // columns expanded into LDS at a time (two buffers)
@@ -477,16 +506,27 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
 
     for (uint32_t vp = 0; vp < nv * (T_FILES / PASS_ROWS); vp++) {
         const uint32_t v = vp / (T_FILES / PASS_ROWS);
+        auto complete = [&](unsigned long long owner, unsigned long long col) {
+            if (U64)
+                complete_pair_u64(a, owner, col);
+            else
+                complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+        };
         const uint32_t wrow = (vp % (T_FILES / PASS_ROWS)) * PASS_ROWS + wave * 32 * MF_RB;  // first tile row of this wave in this pass
         // A fragments: row block rb, slice ks: this lane (row c32, half h) holds the 32 bits of dword 2 ks + h of its row
         v8i A[MF_RB][NK];
 #pragma unroll
         for (int rb = 0; rb < MF_RB; rb++) {
             const unsigned long long owner = row0 + wrow + 32ull * rb + c32;
-            const uint32_t *rp = a.rows + ((owner < a.n ? owner : 0ull) * nv + v) * 8;
+            const uint32_t *rp = a.rows + ((owner < a.n ? owner : 0ull) * nv + v) * HS;
             uint32_t d[8];
-            const uint4 lo = *reinterpret_cast<const uint4 *>(rp);
-            d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w;
+            if (U64) {
+                const uint2 t = *reinterpret_cast<const uint2 *>(rp);
+                d[0] = t.x; d[1] = t.y;
+            } else {
+                const uint4 lo = *reinterpret_cast<const uint4 *>(rp);
+                d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w;
+            }
             if (PW > 4) {
                 const uint4 hi = *reinterpret_cast<const uint4 *>(rp + 4);
                 d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
@@ -507,7 +547,7 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
             for (int q = 0; q < PER_THREAD; q++) {
                 const uint32_t t = threadIdx.x + q * MF_BLOCK;
                 const uint32_t col = t / PW, kb = t % PW;
-                pre[q] = (t < CHUNK * PW && cbase + col < ncols) ? a.cols[(col0 + cbase + col) * 8 + kb] : 0u;
+                pre[q] = (t < CHUNK * PW && cbase + col < ncols) ? a.cols[(col0 + cbase + col) * HS + kb] : 0u;
             }
         };
         auto expand = [&](uint32_t cbase, uint8_t *buf) {
@@ -610,7 +650,7 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
 #pragma unroll 1
                             for (uint32_t r = 0; r < 32; r++) {
                                 const unsigned long long owner = row0 + wrow + 32u * (rb + (r >> 4)) + (r & 3u) + 8u * ((r >> 2) & 3u) + 4u * eh;
-                                if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                                if (owner < a.n) complete(owner, col);
                             }
                         }
                     }
@@ -620,7 +660,7 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
                     const uint32_t ccols = cend - undrained;
                     for (uint32_t t = lane; t < (uint32_t)(32 * MF_RB) * ccols; t += 64) {
                         const unsigned long long owner = row0 + wrow + t / ccols, col = col0 + undrained + t % ccols;
-                        if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
+                        if (owner < a.n) complete(owner, col);
                     }
                 }
                 asm volatile("" ::: "memory");
@@ -802,13 +842,42 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
 }
 
 int rph_launch_hamming64_sweep(const uint64_t *d_hashes, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts,
-                               rph_edge *d_edges, uint64_t cap, unsigned long long *d_count, hipStream_t stream)
+                               rph_edge *d_edges, uint64_t cap, unsigned long long *d_count, hipStream_t stream, int use_mfma)
 {
     if (nparts == 0 || part >= nparts || n > 0xFFFFFFFFull) {
         rph_set_error("hamming64 sweep: bad arguments");
         return RPH_ERR_INVALID_ARG;
     }
     if (n < 2) return RPH_OK;
+    if (use_mfma) {
+        // fp4 MFMA formulation (the whole 64-bit hash is one slice): same kernel as the 256-bit sweep
+        SweepArgs m;
+        m.rows = m.cols = reinterpret_cast<const uint32_t *>(d_hashes);
+        m.low_conf = nullptr;
+        m.has_features = nullptr;
+        m.n = n;
+        m.n_variants = 1;
+        m.threshold = threshold > 64 ? 64 : threshold;
+        m.mih_tol = (threshold / 8u) >= 1 ? 1 : 0;  // chunk_tolerance = max_dist / NUM_CHUNKS (hamminghash.rs:193), NUM_CHUNKS = 8
+        m.part = part;
+        m.nparts = nparts;
+        m.n_tiles = (uint32_t)((n + T_FILES - 1) / T_FILES);
+        const unsigned long long pairs = (unsigned long long)m.n_tiles * (m.n_tiles + 1ull) / 2ull;
+        const unsigned long long S = pairs / (8ull * 768ull * nparts);  // 3 blocks per CU
+        m.seg_tiles = (uint32_t)(S < 1 ? 1 : (S > 8 ? 8 : S));
+        m.n_tile_pairs = seg_G(m.n_tiles, m.seg_tiles);
+        m.edges = d_edges;
+        m.cap = cap;
+        m.count = d_count;
+        const unsigned long long mine = (m.n_tile_pairs > part) ? (m.n_tile_pairs - part + nparts - 1) / nparts : 0;
+        for (unsigned long long b0 = 0; b0 < mine; b0 += MAX_GRID) {
+            m.block0 = b0;
+            hipLaunchKernelGGL((hamming_fp4_kernel<2, true>), dim3((unsigned)((mine - b0) < MAX_GRID ? (mine - b0) : MAX_GRID)), dim3(MF_BLOCK), 0,
+                               stream, m);
+            RPH_HIP_CHECK(hipGetLastError());
+        }
+        return RPH_OK;
+    }
     Sweep64Args a;
     a.hashes = reinterpret_cast<const uint2 *>(d_hashes);
     a.n = n;

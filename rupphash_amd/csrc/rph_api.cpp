@@ -403,7 +403,7 @@ int rph_hamming_all_pairs64_dev(rph_ctx *ctx, const void *d_hashes64, uint64_t n
     }
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
     return rph_launch_hamming64_sweep((const uint64_t *)d_hashes64, n, threshold, part, nparts, (rph_edge *)d_edges, cap,
-                                      (unsigned long long *)d_count, pick(ctx, stream));
+                                      (unsigned long long *)d_count, pick(ctx, stream), ctx->hamming_kernel);
 }
 
 int rph_hamming_all_pairs64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, uint32_t threshold, uint32_t part,
@@ -424,7 +424,7 @@ int rph_hamming_all_pairs64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, 
         RPH_HIP_CHECK(hipMemcpyAsync(d_h.p, hashes64, n * 8, hipMemcpyHostToDevice, ctx->stream));
         RPH_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, 8, ctx->stream));
         RPH_TRY(rph_launch_hamming64_sweep((const uint64_t *)d_h.p, n, threshold, part, nparts, (rph_edge *)d_e.p, cap,
-                                           (unsigned long long *)d_cnt.p, ctx->stream));
+                                           (unsigned long long *)d_cnt.p, ctx->stream, ctx->hamming_kernel));
         unsigned long long cnt = 0;
         RPH_HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));

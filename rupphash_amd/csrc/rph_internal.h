@@ -49,7 +49,7 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
                              const uint8_t *d_has_features, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts, rph_edge *d_edges,
                              uint64_t cap, unsigned long long *d_count, hipStream_t stream, int use_mfma);
 int rph_launch_hamming64_sweep(const uint64_t *d_hashes, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts,
-                               rph_edge *d_edges, uint64_t cap, unsigned long long *d_count, hipStream_t stream);
+                               rph_edge *d_edges, uint64_t cap, unsigned long long *d_count, hipStream_t stream, int use_mfma);
 int rph_launch_mih_build256(rph_ctx *ctx, const uint8_t *d_hashes, uint64_t n, uint32_t *d_offsets, uint32_t *d_values,
                             hipStream_t stream);
 // synth_kernels.hip

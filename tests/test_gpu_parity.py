@@ -488,8 +488,17 @@ def test_u64_reference_tests_on_gpu(eng, oracle):
     assert g and set(int(i) for i in idx) <= set(g[0])
 
 
-@pytest.mark.parametrize("thr", [0, 5, 7, 8, 12, 15, 20])
-def test_u64_find_groups_and_edges_match_oracle(eng, oracle, thr):
+@pytest.mark.parametrize("kernel", [2, 0])  # 2 = fp4 MFMA sweep (default: the 64-bit hash is one MFMA slice), 0 = VALU xor + popcount
+@pytest.mark.parametrize("thr", [0, 5, 7, 8, 12, 15, 20, 31, 40])
+def test_u64_find_groups_and_edges_match_oracle(eng, oracle, thr, kernel):
+    eng.set_hamming_kernel(kernel)
+    try:
+        _u64_case(eng, oracle, thr)
+    finally:
+        eng.set_hamming_kernel(2)
+
+
+def _u64_case(eng, oracle, thr):
     rng = np.random.default_rng(600 + thr)
     n = 3000
     hashes = rng.integers(0, 2**64, n, dtype=np.uint64)
