@@ -236,6 +236,7 @@ __device__ __forceinline__ uint2 expand_byte(uint32_t v)
     return r;
 }
 
+__device__ __forceinline__ int max2i(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int max3i(int a, int b, int c)
 {
     const int ab = a > b ? a : b;
@@ -347,19 +348,22 @@ __global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
                 const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * PW * 16;
 #pragma unroll
                 for (int kb = 0; kb < PW; kb++) B[kb] = *reinterpret_cast<const v4i *>(bp + kb * 16);
-                // max of the 16 accumulators as a tree of v_max3_i32 (depth 3): a linear chain of dependent VALU instructions
-                // issues at ~9 clk each from one wave (tools/valu_dep.hip), independent ones at ~5.6
-                auto max16 = [&](const v16i &acc) {
-                    const int m0 = max3i(acc[0], acc[1], acc[2]), m1 = max3i(acc[3], acc[4], acc[5]), m2 = max3i(acc[6], acc[7], acc[8]);
-                    const int m3 = max3i(acc[9], acc[10], acc[11]), m4 = max3i(acc[12], acc[13], acc[14]);
-                    return max3i(max3i(m0, m1, m2), max3i(m3, m4, acc[15]), m0);
+                // max of the 32 accumulators of the two tiles in 16 instructions: a tree of 15 three-input maxima and one two-input
+                // one (depth 4).  A linear chain of dependent VALU instructions issues at ~9 clk each from one wave
+                // (tools/valu_dep.hip), independent ones at ~5.6.
+                auto max32 = [&](const v16i &p, const v16i &q) {
+                    const auto t0 = max3i(p[0], p[1], p[2]), t1 = max3i(p[3], p[4], p[5]), t2 = max3i(p[6], p[7], p[8]);
+                    const auto t3 = max3i(p[9], p[10], p[11]), t4 = max3i(p[12], p[13], p[14]);
+                    const auto t5 = max3i(q[0], q[1], q[2]), t6 = max3i(q[3], q[4], q[5]), t7 = max3i(q[6], q[7], q[8]);
+                    const auto t8 = max3i(q[9], q[10], q[11]), t9 = max3i(q[12], q[13], q[14]);
+                    const auto u0 = max3i(t0, t1, t2), u1 = max3i(t3, t4, p[15]), u2 = max3i(t5, t6, t7), u3 = max3i(t8, t9, q[15]);
+                    return max2i(max3i(u0, u1, u2), u3);
                 };
                 // One test for the two tiles of a chain pair, and no branch: the lane only sets bit (cb, rb / 2) of its candidate
                 // bitmap of the chunk.  (A branch here, however rare, stalls this wave's MFMA issue and, through the chunk
                 // barriers, its three block mates: 8e6 queue pushes cost 10 ms at threshold 40.)
                 auto screen2 = [&](const v16i &a0, const v16i &a1, int rb) {
-                    const int ma = max16(a0), mb = max16(a1);
-                    cand |= ((ma > mb ? ma : mb) >= thresh_dot) ? (1u << (cb * (MF_RB / 2) + rb / 2)) : 0u;
+                    cand |= (max32(a0, a1) >= thresh_dot) ? (1u << (cb * (MF_RB / 2) + rb / 2)) : 0u;
                 };
                 // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
                 // independent one every 32: tools/mfma_rate.hip)
@@ -587,19 +591,22 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
                     const v4i t = *reinterpret_cast<const v4i *>(bp + ks * 16);
                     B[ks] = v8i{t[0], t[1], t[2], t[3], 0, 0, 0, 0};
                 }
-                // max of the 16 accumulators as a tree of v_max3_f32 (depth 3; exact integers, no NaNs): a linear chain of dependent VALU instructions
-                // issues at ~9 clk each from one wave (tools/valu_dep.hip), independent ones at ~5.6
-                auto max16 = [&](const v16f &acc) {
-                    const float m0 = max3f(acc[0], acc[1], acc[2]), m1 = max3f(acc[3], acc[4], acc[5]), m2 = max3f(acc[6], acc[7], acc[8]);
-                    const float m3 = max3f(acc[9], acc[10], acc[11]), m4 = max3f(acc[12], acc[13], acc[14]);
-                    return max3f(max3f(m0, m1, m2), max3f(m3, m4, acc[15]), m0);
+                // max of the 32 accumulators of the two tiles in 16 instructions: a tree of 15 three-input maxima and one two-input
+                // one (depth 4).  A linear chain of dependent VALU instructions issues at ~9 clk each from one wave
+                // (tools/valu_dep.hip), independent ones at ~5.6.
+                auto max32 = [&](const v16f &p, const v16f &q) {
+                    const auto t0 = max3f(p[0], p[1], p[2]), t1 = max3f(p[3], p[4], p[5]), t2 = max3f(p[6], p[7], p[8]);
+                    const auto t3 = max3f(p[9], p[10], p[11]), t4 = max3f(p[12], p[13], p[14]);
+                    const auto t5 = max3f(q[0], q[1], q[2]), t6 = max3f(q[3], q[4], q[5]), t7 = max3f(q[6], q[7], q[8]);
+                    const auto t8 = max3f(q[9], q[10], q[11]), t9 = max3f(q[12], q[13], q[14]);
+                    const auto u0 = max3f(t0, t1, t2), u1 = max3f(t3, t4, p[15]), u2 = max3f(t5, t6, t7), u3 = max3f(t8, t9, q[15]);
+                    return __builtin_fmaxf(max3f(u0, u1, u2), u3);
                 };
                 // One test for the two tiles of a chain pair, and no branch: the lane only sets bit (cb, rb / 2) of its candidate
                 // bitmap of the chunk.  (A branch here, however rare, stalls this wave's MFMA issue and, through the chunk
                 // barriers, its three block mates: 8e6 queue pushes cost 10 ms at threshold 40.)
                 auto screen2 = [&](const v16f &a0, const v16f &a1, int rb) {
-                    const float ma = max16(a0), mb = max16(a1);
-                    cand |= ((ma > mb ? ma : mb) >= thresh_dot) ? (1u << (cb * (MF_RB / 2) + rb / 2)) : 0u;
+                    cand |= (max32(a0, a1) >= thresh_dot) ? (1u << (cb * (MF_RB / 2) + rb / 2)) : 0u;
                 };
                 // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
                 // independent one every 32: tools/mfma_rate.hip)
