@@ -2,7 +2,8 @@
 
     PDQ_MIN_QUALITY, is_low_pdq_quality            scanner.rs:1588-1594
     group_with_pdqhash / group_files_generic       scanner.rs:1640-1832 up to the union-find
-File-name logic after the union-find (merge_groups_by_stem, process_raw_groups) stays with the caller.
+    group_max_dist                                 scanner.rs:2214-2241 (the per-group max_dist of process_raw_groups)
+File-name logic after the union-find (merge_groups_by_stem, the sorting inside process_raw_groups) stays with the caller.
 """
 import numpy as np
 
@@ -27,3 +28,35 @@ def group_with_pdqhash(hashes, similarity, coefficients=None, has_features=None,
     groups by first member) of the edge set of group_files_generic::<[u8;32], PdqStrategy>."""
     q = None if quality is None else np.array([-1 if x is None else int(x) for x in quality], np.int32)
     return (engine or default_engine()).group_files_pdq(hashes, similarity, coefficients, has_features, q)
+
+
+def group_max_dist(groups, hashes, pivots, coefficients=None, has_features=None, engine=None):
+    """Per-group `max_dist` of process_raw_groups (scanner.rs:2214-2241).
+
+    `groups`: lists of file indices (in the caller's display order: the reference sorts by file name first, which stays with
+    the caller); `pivots[g]`: index of the group's pivot file, i.e. the first file of the sorted group that has features, else
+    the first that has a hash (the caller's find_map), or None.  With features the distance of a member is the minimum over
+    the pivot's 8 dihedral hashes (one batched rph_pdq_hashes_from_coeffs for all pivots), otherwise the plain distance to the
+    pivot's hash; the group's value is the maximum over its members that have a hash (here: all listed members)."""
+    eng = engine or default_engine()
+    hashes = np.ascontiguousarray(hashes, np.uint8).reshape(-1, 32)
+    bits = np.unpackbits(hashes, axis=1)
+    out = [0] * len(groups)
+    with_feats = [g for g, p in enumerate(pivots)
+                  if p is not None and coefficients is not None and (has_features is None or has_features[p])]
+    variants = {}
+    if with_feats:
+        c = np.ascontiguousarray(np.asarray(coefficients, np.float32).reshape(-1, 256)[[pivots[g] for g in with_feats]])
+        _, dih = eng.pdq_hashes_from_coeffs(c, want_hash=False, want_dihedral=True)
+        variants = {g: np.unpackbits(dih[k], axis=1) for k, g in enumerate(with_feats)}
+    for g, members in enumerate(groups):
+        p = pivots[g]
+        if p is None or not len(members):
+            continue
+        mb = bits[np.asarray(members, np.int64)]
+        if g in variants:
+            d = (mb[:, None, :] != variants[g][None, :, :]).sum(axis=2).min(axis=1)
+        else:
+            d = (mb != bits[p][None, :]).sum(axis=1)
+        out[g] = int(d.max())
+    return out

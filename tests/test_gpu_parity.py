@@ -682,3 +682,33 @@ def test_pdq_random_geometries_match_oracle(eng, oracle):
             assert bits(quality[k:k + 1])[0] == bits(np.float32(q))[()], (case, w, h, ch, k)
             assert np.array_equal(hashes[k], oracle.to_hash(c)), (case, w, h, ch, k)
             assert np.array_equal(dihedral[k], oracle.dihedral_hashes(c)), (case, w, h, ch, k)
+
+
+def test_group_max_dist_matches_reference_rule(eng, oracle):
+    """scanner.rs:2214-2241: max over members of the min distance to the pivot's 8 dihedral hashes (or to its plain hash)"""
+    from rupphash_amd import scanner
+    rng = np.random.default_rng(8)
+    n = 40
+    coeffs = rng.normal(0, 30, (n, 256)).astype(np.float32)
+    hashes = np.stack([oracle.to_hash(c) for c in coeffs])
+    # members 1..4 of group 0 are dihedral variants of file 0 with a few bits flipped
+    dih0 = oracle.dihedral_hashes(coeffs[0])
+    for k, slot in zip((1, 2, 3, 4), (1, 3, 5, 7)):
+        h = dih0[slot].copy()
+        for b in rng.choice(256, k, replace=False):
+            h[b >> 3] ^= 1 << (b & 7)
+        hashes[k] = h
+    groups = [[0, 1, 2, 3, 4], [10, 11, 12], [20, 21]]
+    pivots = [0, 11, None]
+    got = scanner.group_max_dist(groups, hashes, pivots, coefficients=coeffs, engine=eng)
+    want = []
+    for g, p in zip(groups, pivots):
+        if p is None:
+            want.append(0)
+            continue
+        var = oracle.dihedral_hashes(coeffs[p])
+        want.append(max(min(oracle.hamming256(v, hashes[m]) for v in var) for m in g))
+    assert got == want and got[0] == 4
+    # without features: plain distance to the pivot's hash
+    got2 = scanner.group_max_dist(groups, hashes, pivots, engine=eng)
+    assert got2 == [max(oracle.hamming256(hashes[p], hashes[m]) for m in g) if p is not None else 0 for g, p in zip(groups, pivots)]
