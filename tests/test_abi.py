@@ -127,3 +127,32 @@ def test_host_grouping_from_edges_matches_oracle(oracle, thr):
     eng.ctx = None
     assert eng.find_groups_from_edges(edges, n) == oracle.find_groups(oracle.KIND_PDQ, hashes, thr)
     assert eng.union_find_groups(edges, n) == oracle.group_pdq(hashes, thr)[1]
+
+
+def _build_c_consumer():
+    import subprocess
+    out = os.path.join(ROOT, "tests", "c", "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", out, "-L", os.path.join(ROOT, "rupphash_amd"),
+                           "-lrupphash_hip", "-Wl,-rpath," + os.path.join(ROOT, "rupphash_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+def test_header_is_plain_c_and_links():
+    """include/rupphash.h compiles as strict C99 and a C program links against the library; without a GPU rph_init fails loudly"""
+    import subprocess
+    exe = _build_c_consumer()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+        assert "no device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_consumer_runs_on_gpu():
+    import subprocess
+    exe = _build_c_consumer()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "distance between the two images" in r.stdout
