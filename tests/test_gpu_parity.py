@@ -712,3 +712,38 @@ def test_group_max_dist_matches_reference_rule(eng, oracle):
     # without features: plain distance to the pivot's hash
     got2 = scanner.group_max_dist(groups, hashes, pivots, engine=eng)
     assert got2 == [max(oracle.hamming256(hashes[p], hashes[m]) for m in g) if p is not None else 0 for g, p in zip(groups, pivots)]
+
+
+def test_one_context_from_many_threads(eng, oracle):
+    """The C ABI is thread-safe per context (the reference's entry points are called from arbitrary rayon threads): hashing,
+    sweeping and grouping run concurrently from 6 threads on one context and every thread gets its own exact answer."""
+    import threading
+    rng = np.random.default_rng(99)
+    imgs = rng.integers(0, 256, (6, 3, 120, 90, 3), dtype=np.uint8)
+    hsets = [clustered_hashes(np.random.default_rng(700 + t), 1500, 40, 40) for t in range(6)]
+    out = [None] * 6
+    errs = []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                r = eng.pdq_hash_batch(imgs[t], want_coeffs=True)
+                e = eng.hamming_all_pairs(hsets[t], 32)
+                g = eng.find_groups256(hsets[t], 31)
+                out[t] = (r, e, g)
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(6):
+        r, e, g = out[t]
+        for k in range(3):
+            rc, c, q = oracle.pdq_features(imgs[t][k])
+            assert np.array_equal(bits(r["coeffs"][k]), bits(c)) and np.array_equal(r["hash"][k], oracle.to_hash(c))
+        assert edge_set(e) == sorted(map(tuple, oracle.all_pairs256(hsets[t], 32).tolist()))
+        assert g == oracle.find_groups(oracle.KIND_PDQ, hsets[t], 31)
