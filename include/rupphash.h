@@ -269,6 +269,12 @@ int rph_dev_upload(rph_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 int rph_dev_download(rph_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int rph_dev_memset(rph_ctx *ctx, void *d_dst, int value, size_t bytes, void *stream);
 
+/* Extra streams for callers without a HIP binding: the _dev entry points are asynchronous on the stream they are given, and
+ * work given to different streams may overlap (the library orders its own shared scratch behind the previous user). */
+int rph_stream_create(rph_ctx *ctx, void **stream_out);
+int rph_stream_synchronize(rph_ctx *ctx, void *stream);
+int rph_stream_destroy(rph_ctx *ctx, void *stream);
+
 /* Timing hooks used by bench.py: HIP events recorded on `stream` (NULL = the
  * context's stream), so the measured interval is the kernels' own stream time. */
 int rph_event_create(rph_ctx *ctx, void **event_out);

@@ -94,6 +94,9 @@ SIGNATURES = {
     "rph_dev_upload": (C.c_int, [_vp, _vp, _vp, _sz]),
     "rph_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
     "rph_dev_memset": (C.c_int, [_vp, _vp, C.c_int, _sz, _vp]),
+    "rph_stream_create": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "rph_stream_synchronize": (C.c_int, [_vp, _vp]),
+    "rph_stream_destroy": (C.c_int, [_vp, _vp]),
     "rph_event_create": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "rph_event_record": (C.c_int, [_vp, _vp, _vp]),
     "rph_event_elapsed_ms": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float)]),

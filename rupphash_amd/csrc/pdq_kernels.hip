@@ -177,14 +177,18 @@ int rph_launch_pdq_generic(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
     if (chunk > n) chunk = n;
     const size_t need = 2 * plane_bytes * chunk;
     if (ctx->scratch_bytes < need) {
-        // the generic path owns its stream order: make sure earlier work using the old scratch is done
-        RPH_HIP_CHECK(hipStreamSynchronize(stream));
+        // kernels of any stream may still be using the old scratch
+        RPH_HIP_CHECK(hipDeviceSynchronize());
         if (ctx->scratch) RPH_HIP_CHECK(hipFree(ctx->scratch));
         ctx->scratch = nullptr;
         ctx->scratch_bytes = 0;
         RPH_HIP_CHECK(hipMalloc((void **)&ctx->scratch, need));
         ctx->scratch_bytes = need;
     }
+    // one scratch for all caller streams (the caller holds ctx->mu while enqueueing): order this launch behind the previous
+    // user's kernels if they went to another stream
+    if (!ctx->scratch_done) RPH_HIP_CHECK(hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));
+    if (ctx->scratch_used && ctx->scratch_stream != stream) RPH_HIP_CHECK(hipStreamWaitEvent(stream, ctx->scratch_done, 0));
     float *a = ctx->scratch, *b = ctx->scratch + (size_t)chunk * w * h;
     const uint32_t win_rows = (w + 63) / 64;  // window along rows = ceil(cols / 64)   pdqhash.rs:246
     const uint32_t win_cols = (h + 63) / 64;  // window along cols = ceil(rows / 64)   pdqhash.rs:247
@@ -206,5 +210,8 @@ int rph_launch_pdq_generic(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
                            d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr);
         RPH_HIP_CHECK(hipGetLastError());
     }
+    RPH_HIP_CHECK(hipEventRecord(ctx->scratch_done, stream));
+    ctx->scratch_stream = stream;
+    ctx->scratch_used = true;
     return RPH_OK;
 }

@@ -184,6 +184,7 @@ int rph_shutdown(rph_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->sink) (void)hipFree(ctx->sink);
+    if (ctx->scratch_done) (void)hipEventDestroy(ctx->scratch_done);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RPH_OK;
@@ -635,6 +636,35 @@ int rph_dev_memset(rph_ctx *ctx, void *d_dst, int value, size_t bytes, void *str
     if (!ctx || (!d_dst && bytes)) return RPH_ERR_INVALID_ARG;
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
     RPH_HIP_CHECK(hipMemsetAsync(d_dst, value, bytes, pick(ctx, stream)));
+    return RPH_OK;
+}
+
+int rph_stream_create(rph_ctx *ctx, void **stream_out)
+{
+    if (!ctx || !stream_out) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = nullptr;
+    RPH_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream_out = s;
+    return RPH_OK;
+}
+
+int rph_stream_synchronize(rph_ctx *ctx, void *stream)
+{
+    if (!ctx) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    RPH_HIP_CHECK(hipStreamSynchronize(pick(ctx, stream)));
+    return RPH_OK;
+}
+
+int rph_stream_destroy(rph_ctx *ctx, void *stream)
+{
+    if (!ctx || !stream) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RPH_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    if (ctx->scratch_stream == (hipStream_t)stream) ctx->scratch_used = false;  // its work is complete: nothing left to order behind
+    RPH_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
     return RPH_OK;
 }
 

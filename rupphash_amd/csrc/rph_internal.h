@@ -17,6 +17,10 @@ struct rph_ctx {
     float *scratch = nullptr;
     size_t scratch_bytes = 0;
     uint32_t *sink = nullptr;  // 4-byte result slot of the read-stream probe
+    // the scratch planes are shared by every caller stream: a launch on another stream first waits for the last user's event
+    hipEvent_t scratch_done = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
     int hamming_kernel = 2;  // 2 = fp4 MFMA formulation of the sweep's fast path (default), 1 = int8 MFMA, 0 = VALU xor + popcount
     int pdq_kernel = 1;  // 0 = always generic; 1 / 2 = fused 512x512x3 kernel (64- / 128-px strips) where it applies
 };

@@ -282,6 +282,17 @@ class Engine:
         """one pure read pass over a device buffer (bench.py times it: the read bandwidth a streaming kernel can get)"""
         check(self.L.rph_read_stream_dev(self.ctx, d_buf, nbytes, stream), "rph_read_stream_dev")
 
+    def stream_create(self):
+        s = C.c_void_p()
+        check(self.L.rph_stream_create(self.ctx, C.byref(s)), "rph_stream_create")
+        return s
+
+    def stream_synchronize(self, stream=None):
+        check(self.L.rph_stream_synchronize(self.ctx, stream), "rph_stream_synchronize")
+
+    def stream_destroy(self, stream):
+        check(self.L.rph_stream_destroy(self.ctx, stream), "rph_stream_destroy")
+
     def dev_alloc(self, nbytes):
         p = C.c_void_p()
         check(self.L.rph_dev_alloc(self.ctx, nbytes, C.byref(p)), "rph_dev_alloc")

@@ -747,3 +747,33 @@ def test_one_context_from_many_threads(eng, oracle):
             assert np.array_equal(bits(r["coeffs"][k]), bits(c)) and np.array_equal(r["hash"][k], oracle.to_hash(c))
         assert edge_set(e) == sorted(map(tuple, oracle.all_pairs256(hsets[t], 32).tolist()))
         assert g == oracle.find_groups(oracle.KIND_PDQ, hsets[t], 31)
+
+
+def test_generic_path_on_two_caller_streams(eng, oracle):
+    """rph_pdq_hash_batch_dev is asynchronous on the caller's stream; the generic kernels share one scratch per context, so launches
+    on different streams must be ordered behind each other (event chaining), not race on it."""
+    rng = np.random.default_rng(31)
+    sets = [rng.integers(0, 256, (24, 200, 160, 3), dtype=np.uint8), rng.integers(0, 256, (24, 200, 160, 3), dtype=np.uint8)]
+    streams = [eng.stream_create(), eng.stream_create()]
+    d_px = [eng.dev_alloc(s.nbytes) for s in sets]
+    d_h = [eng.dev_alloc(24 * 32) for _ in sets]
+    try:
+        for k in range(2):
+            eng.dev_upload(d_px[k], sets[k])
+        eng.synchronize()
+        for rep in range(20):  # interleave launches on the two streams without any host synchronisation
+            for k in range(2):
+                eng.pdq_hash_batch_dev(d_px[k], 24, 160, 200, 3, d_h[k], stream=streams[k])
+        for st in streams:
+            eng.stream_synchronize(st)
+        for k in range(2):
+            got = np.zeros((24, 32), np.uint8)
+            eng.dev_download(got, d_h[k])
+            for i in range(24):
+                rc, c, _ = oracle.pdq_features(sets[k][i])
+                assert np.array_equal(got[i], oracle.to_hash(c)), (k, i)
+    finally:
+        for p in d_px + d_h:
+            eng.dev_free(p)
+        for st in streams:
+            eng.stream_destroy(st)
