@@ -13,9 +13,13 @@
  *   - one rph_ctx per process and GPU (one process per GPU; multi-GPU sharding is
  *     done by the caller's launcher, see rupphash_amd/dist.py); a context is
  *     thread-safe: calls on one context are serialised internally
- *   - `*_dev` twins take DEVICE pointers and a hipStream_t (as void*), enqueue
- *     asynchronously and never synchronise; host-pointer versions stage through
- *     device memory and return when the result is in the caller's buffer
+ *   - `*_dev` twins take DEVICE pointers and a hipStream_t (as void*) and enqueue
+ *     asynchronously on it (work given to different streams may overlap; the library
+ *     orders its own shared scratch between them).  They do not synchronise, with one
+ *     exception: rph_pdq_hash_batch_dev on images larger than 512 px allocates and frees
+ *     its thumbnail buffers per call, and hipFree waits for the device.  Host-pointer
+ *     versions stage through device memory and return when the result is in the
+ *     caller's buffer
  *   - there is no CPU fallback: if no gfx950 device is usable, rph_init fails
  */
 #ifndef RUPPHASH_H
