@@ -592,6 +592,8 @@ def _strided_batch(rng, n, h, w, ch, row_stride, image_stride):
 @pytest.mark.parametrize("w,h,ch,row_pad,img_pad,which", [
     (512, 512, 3, 64, 4096, 1),    # fused strip64 with padded rows and a gap between images
     (512, 512, 3, 128, 0, 2),      # fused strip128, rows padded, images back to back
+    (512, 512, 3, 4, 4, 1),        # fused kernel with rows that are only 4-byte aligned (dwordx4 loads at 4-byte alignment)
+    (512, 512, 3, 12, 8, 2),
     (512, 512, 3, 1, 3, 1),        # row stride 1537: not a multiple of 4 -> generic kernel must take over
     (100, 37, 3, 5, 11, 1),        # generic kernel
     (64, 64, 1, 3, 0, 1),          # Luma8
