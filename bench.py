@@ -216,12 +216,12 @@ def main():
         # against the dense fp4 peak (2 x the fp8 / int8 peak)
         h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": 2 * MFMA_I8_OPS_PER_S / 1e12, "unit": "TOP/s (fp4)",
                   "frac": pairs_per_s_rank * 64 * pw / (2 * MFMA_I8_OPS_PER_S), "int8_equivalent_ops_per_pair": 64 * pw, "prefix_dwords": pw, "hbm_bytes_per_pair": 64.0 / 1024,
-                  "kernel_ms": h_kernel_ms, "kernel": "hamming_fp4_kernel"}
+                  "kernel_ms": h_kernel_ms, "kernel": "hamming_mfma_kernel<FmtFp4>"}
     elif args.hamming_kernel == 1:
         # int8 MFMA fast path: one v_mfma_i32_32x32x32_i8 (65 536 int8 ops) per 32-bit slice of 1024 pairs -> 64 * PW ops per pair
         h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": MFMA_I8_OPS_PER_S / 1e12,
                   "unit": "TOP/s (int8)", "frac": pairs_per_s_rank * 64 * pw / MFMA_I8_OPS_PER_S, "prefix_dwords": pw,
-                  "int8_ops_per_pair": 64 * pw, "hbm_bytes_per_pair": 64.0 / 1024, "kernel_ms": h_kernel_ms, "kernel": "hamming_mfma_kernel"}
+                  "int8_ops_per_pair": 64 * pw, "hbm_bytes_per_pair": 64.0 / 1024, "kernel_ms": h_kernel_ms, "kernel": "hamming_mfma_kernel<FmtI8>"}
     else:
         lane_ops = 2 * pw * pairs_per_s_rank  # executed xor + bcnt lane-ops/s on this rank
         h_roof = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12, "unit": "Tlane-op/s",

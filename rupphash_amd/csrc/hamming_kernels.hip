@@ -23,14 +23,14 @@
 // The binding roof is integer VALU (2*PW lane-ops per pair), not HBM: the sweep
 // moves 64/T bytes per pair.
 //
-// Second formulation of the same fast path (default): hamming_mfma_kernel.  With bits encoded as
-// +-1 bytes, a 32-bit slice of the XOR-popcount is an int8 dot product: dot = 32 - 2 d.  One
-// v_mfma_i32_32x32x32_i8 therefore evaluates a 32-bit slice for 32 x 32 pairs in 32 cycles on the
-// matrix pipe (8 pairs/clk/SIMD per slice against 64 lanes / 6 clk for v_xor + v_bcnt, which is a
-// half-rate VALU op on gfx950 -- tools/valu_rate.hip), exactly (int32 accumulation), and the VALU
-// is left with one max-reduction per tile.  Row fragments stay in VGPRs, the column tile is
-// expanded to +-1 bytes once per chunk through a 256-entry LUT in LDS.  Candidates (partial
-// distance <= threshold) go through the same exact completion as the VALU kernel.
+// Default formulation of the same fast path: hamming_mfma_kernel<Format, PW>.  With bits encoded as +-1, a slice of the
+// XOR-popcount is a dot product (dot = bits - 2 d), exact in the accumulator, so the matrix pipe evaluates 32 x 32 pairs per
+// instruction and the VALU is left with one max-reduction per tile:
+//   FmtFp4 (default)  e2m1 codes 0x2 / 0xA, v_mfma_scale_f32_32x32x64_f8f6f4 at unit scales: a 64-bit slice in 32 clk
+//   FmtI8             int8 bytes, v_mfma_i32_32x32x32_i8: a 32-bit slice in 32 clk
+// (against 64 lanes / 6 clk for v_xor + v_bcnt, a half-rate VALU op on gfx950 -- tools/valu_rate.hip).  Row fragments stay in
+// VGPRs, column chunks are expanded once through a 256-entry LUT into LDS.  Candidates (partial distance <= threshold) go through
+// the same exact completion as the VALU kernel.  64-bit hashes use the fp4 format with the whole hash as one slice.
 #include "rph_internal.h"
 
 namespace {
@@ -243,199 +243,86 @@ __device__ __forceinline__ int max3i(int a, int b, int c)
     return ab > c ? ab : c;
 }
 
-template <int PW>
-__global__ void __launch_bounds__(MF_BLOCK, 2) hamming_mfma_kernel(SweepArgs a)
-{
-    constexpr int PITCH = 2 * PW * 16 + 16;  // bytes per column: [k-half h][dword kb][16 x i8] + pad (conflict-free b128, lane = column)
-    constexpr int CHUNK = PW <= 4 ? 256 : 128;  // columns expanded into LDS at a time (two buffers)
-    constexpr int QCAP = 128;                // candidate queue per wave (entries of 8 bytes); overflow falls back to an exhaustive completion
-    constexpr int MF_RB = PW <= 4 ? 8 : 4;   // 32-row blocks per wave and pass (A fragments: MF_RB * PW * 4 VGPRs)
-    constexpr int PASS_ROWS = 4 * 32 * MF_RB; // rows one pass of the 4 waves covers; T_FILES / PASS_ROWS passes per tile
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * CHUNK * PITCH];
-    __shared__ uint2 s_lut[256];
-    __shared__ uint2 s_q[4][QCAP];      // one queue per wave: filled and drained by the same wave, no barrier needed
-    __shared__ uint32_t s_qn[4];
-
-    // one block = row tile I against the column tiles [J0, J0 + seg_tiles): the row fragments are built once, and the wait for
-    // the (rare) candidates' exact completion is paid once per segment instead of once per tile
-    const unsigned long long p = (unsigned long long)a.part + (a.block0 + blockIdx.x) * a.nparts;
-    if (p >= a.n_tile_pairs) return;  // (for this kernel: the number of segment blocks)
-    uint32_t I, J;
-    seg_block(p, a.n_tiles, a.seg_tiles, I, J);
-    const unsigned long long col0 = (unsigned long long)J * T_FILES;
-    const unsigned long long row0 = (unsigned long long)I * T_FILES;
-    const unsigned long long seg_cols = (unsigned long long)a.seg_tiles * T_FILES;
-    const uint32_t ncols = (uint32_t)((a.n - col0) < seg_cols ? (a.n - col0) : seg_cols);  // <= 8192: queue entries keep 16 bits for it
-
-    s_lut[threadIdx.x] = expand_byte(threadIdx.x);
-    if (threadIdx.x < 4) s_qn[threadIdx.x] = 0;
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c32 = lane & 31, h = lane >> 5;
-    const int thresh_dot = 32 * PW - 2 * (int)a.threshold;  // partial distance <= threshold  <=>  dot >= 32 PW - 2 threshold
-    const uint32_t nv = a.n_variants;
-
-    for (uint32_t vp = 0; vp < nv * (T_FILES / PASS_ROWS); vp++) {
-        const uint32_t v = vp / (T_FILES / PASS_ROWS);
-        const uint32_t wrow = (vp % (T_FILES / PASS_ROWS)) * PASS_ROWS + wave * 32 * MF_RB;  // first tile row of this wave in this pass
-        // A fragments: row block rb, dword kb: this lane (row c32, half h) holds the 16 bits [32 kb + 16 h, +16) of its row
-        v4i A[MF_RB][PW];
-#pragma unroll
-        for (int rb = 0; rb < MF_RB; rb++) {
-            const unsigned long long owner = row0 + wrow + 32ull * rb + c32;
-            const uint32_t *rp = a.rows + ((owner < a.n ? owner : 0ull) * nv + v) * 8;
-            uint32_t d[8];
-            const uint4 lo = *reinterpret_cast<const uint4 *>(rp);
-            d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w;
-            if (PW > 4) {
-                const uint4 hi = *reinterpret_cast<const uint4 *>(rp + 4);
-                d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
-            }
-#pragma unroll
-            for (int kb = 0; kb < PW; kb++) {
-                const uint32_t hw = (d[kb] >> (16 * h)) & 0xFFFFu;
-                const uint2 e0 = s_lut[hw & 0xFFu], e1 = s_lut[hw >> 8];
-                A[rb][kb] = v4i{(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
-            }
-        }
-
-        // column chunks are double buffered: the packed dwords of chunk i + 1 are fetched into registers while chunk i
-        // is swept and expanded into the other LDS buffer afterwards, so global latency never sits between two chunks
-        constexpr int PER_THREAD = (CHUNK * PW + MF_BLOCK - 1) / MF_BLOCK;
-        uint32_t pre[PER_THREAD];
-        auto fetch = [&](uint32_t cbase) {
-#pragma unroll
-            for (int q = 0; q < PER_THREAD; q++) {
-                const uint32_t t = threadIdx.x + q * MF_BLOCK;
-                const uint32_t col = t / PW, kb = t % PW;
-                pre[q] = (t < CHUNK * PW && cbase + col < ncols) ? a.cols[(col0 + cbase + col) * 8 + kb] : 0u;
-            }
-        };
-        auto expand = [&](uint32_t cbase, uint8_t *buf) {
-#pragma unroll
-            for (int q = 0; q < PER_THREAD; q++) {
-                const uint32_t t = threadIdx.x + q * MF_BLOCK;
-                if (t >= CHUNK * PW) continue;
-                const uint32_t col = t / PW, kb = t % PW;
-                const bool live = cbase + col < ncols;
-                uint8_t *dst = buf + col * PITCH + kb * 16;
-#pragma unroll
-                for (int hh = 0; hh < 2; hh++) {
-                    const uint32_t hw = (pre[q] >> (16 * hh)) & 0xFFFFu;
-                    uint2 e0 = s_lut[hw & 0xFFu], e1 = s_lut[hw >> 8];
-                    if (!live) e0 = e1 = make_uint2(0, 0);  // zero bytes: dot 0, never a candidate unless every pair is
-                    *reinterpret_cast<uint4 *>(dst + hh * PW * 16) = make_uint4(e0.x, e0.y, e1.x, e1.y);
-                }
-            }
-        };
-        fetch(0);
-        int which = 0;
-        uint32_t undrained = 0;
-        for (uint32_t cbase = 0; cbase < ncols; cbase += CHUNK, which ^= 1) {
-            uint8_t *s_b = s_buf + which * (CHUNK * PITCH);
-            expand(cbase, s_b);
-            __syncthreads();  // chunk visible (and the queue reset of the previous chunk)
-            if (cbase + CHUNK < ncols) fetch(cbase + CHUNK);
-
-            // ---- fast path: MFMA + VALU screen only.  No global memory operation lives in this loop (candidates go to
-            // an LDS queue), so the compiler never has to drain vmcnt here and the prefetch above stays in flight.
-            uint32_t cand = 0;  // bit (cb * MF_RB / 2 + rb / 2): this lane saw a candidate among its 32 pairs of column block cb, row blocks rb, rb + 1
-#pragma unroll 1
-            for (int cb = 0; cb < CHUNK / 32; cb++) {
-                if (cbase + cb * 32 >= ncols) break;
-                v4i B[PW];
-                const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * PW * 16;
-#pragma unroll
-                for (int kb = 0; kb < PW; kb++) B[kb] = *reinterpret_cast<const v4i *>(bp + kb * 16);
-                // max of the 32 accumulators of the two tiles in 16 instructions: a tree of 15 three-input maxima and one two-input
-                // one (depth 4).  A linear chain of dependent VALU instructions issues at ~9 clk each from one wave
-                // (tools/valu_dep.hip), independent ones at ~5.6.
-                auto max32 = [&](const v16i &p, const v16i &q) {
-                    const auto t0 = max3i(p[0], p[1], p[2]), t1 = max3i(p[3], p[4], p[5]), t2 = max3i(p[6], p[7], p[8]);
-                    const auto t3 = max3i(p[9], p[10], p[11]), t4 = max3i(p[12], p[13], p[14]);
-                    const auto t5 = max3i(q[0], q[1], q[2]), t6 = max3i(q[3], q[4], q[5]), t7 = max3i(q[6], q[7], q[8]);
-                    const auto t8 = max3i(q[9], q[10], q[11]), t9 = max3i(q[12], q[13], q[14]);
-                    const auto u0 = max3i(t0, t1, t2), u1 = max3i(t3, t4, p[15]), u2 = max3i(t5, t6, t7), u3 = max3i(t8, t9, q[15]);
-                    return max2i(max3i(u0, u1, u2), u3);
-                };
-                // One test for the two tiles of a chain pair, and no branch: the lane only sets bit (cb, rb / 2) of its candidate
-                // bitmap of the chunk.  (A branch here, however rare, stalls this wave's MFMA issue and, through the chunk
-                // barriers, its three block mates: 8e6 queue pushes cost 10 ms at threshold 40.)
-                auto screen2 = [&](const v16i &a0, const v16i &a1, int rb) {
-                    cand |= (max32(a0, a1) >= thresh_dot) ? (1u << (cb * (MF_RB / 2) + rb / 2)) : 0u;
-                };
-                // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
-                // independent one every 32: tools/mfma_rate.hip)
-#pragma unroll
-                for (int rb = 0; rb < MF_RB; rb += 2) {
-                    v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    v16i acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int kb = 0; kb < PW; kb++) {
-                        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[rb][kb], B[kb], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[rb + 1][kb], B[kb], acc1, 0, 0, 0);
-                    }
-                    screen2(acc0, acc1, rb);
-                }
-            }
-
-            // ---- lanes with candidates append (bitmap, column) to the wave's queue: slots by ballot rank, no atomics
-            // (wave-local: the LDS executes one wave's operations in order, so no barrier is needed between push, read and reset)
-            asm volatile("" ::: "memory");
-            const unsigned long long vote = __builtin_amdgcn_ballot_w64(cand != 0);
-            uint32_t nq = s_qn[wave];
-            if (vote != 0) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
-                const uint32_t slot = nq + rank;
-                if (cand != 0 && slot < QCAP) s_q[wave][slot] = make_uint2(cand, ((uint32_t)h << 16) | (cbase + c32));
-                nq += (uint32_t)__builtin_popcountll(vote);
-                if (lane == 0) s_qn[wave] = nq;
-                asm volatile("" ::: "memory");
-            }
-            // ---- complete the queued candidates exactly.  A drain costs a global-memory round trip whatever it holds, so it waits
-            // until a full wave of entries is queued or the pass ends; `undrained` is the first column of the segment whose
-            // candidates may still sit in the queue.
-            const uint32_t cend = (cbase + CHUNK) < ncols ? (cbase + CHUNK) : ncols;
-            if (nq == 0) {
-                undrained = cend;
-            } else if (nq >= 64 || cend == ncols) {
-                if (nq <= QCAP) {
-                    for (uint32_t t = lane; t < nq; t += 64) {
-                        const uint2 e = s_q[wave][t];
-                        const uint32_t eh = e.y >> 16;
-                        uint32_t bm = e.x;
-                        while (bm != 0) {
-                            const uint32_t bit = (uint32_t)__builtin_ctz(bm);
-                            bm &= bm - 1;
-                            const uint32_t rb = 2u * (bit % (MF_RB / 2));
-                            const unsigned long long col = col0 + (e.y & 0xFFFFu) + 32u * (bit / (MF_RB / 2));
-                            // the 32 pairs of that lane: C/D layout of the two tiles: row = (r & 3) + 8 (r >> 2) + 4 h
-#pragma unroll 1
-                            for (uint32_t r = 0; r < 32; r++) {
-                                const unsigned long long owner = row0 + wrow + 32u * (rb + (r >> 4)) + (r & 3u) + 8u * ((r >> 2) & 3u) + 4u * eh;
-                                if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
-                            }
-                        }
-                    }
-                } else {
-                    // queue overflow (heavily duplicated data): every pair of this wave's rows and the columns since the last
-                    // drain is completed exactly
-                    const uint32_t ccols = cend - undrained;
-                    for (uint32_t t = lane; t < (uint32_t)(32 * MF_RB) * ccols; t += 64) {
-                        const unsigned long long owner = row0 + wrow + t / ccols, col = col0 + undrained + t % ccols;
-                        if (owner < a.n) complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
-                    }
-                }
-                asm volatile("" ::: "memory");
-                if (lane == 0) s_qn[wave] = 0;
-                undrained = cend;
-            }
-        }
-        __syncthreads();  // the last chunk's buffers and queue are free before the next pass starts
+// ---- the two matrix formats.  A format says how a packed hash dword becomes MFMA operand bytes (through a 256-entry LUT in LDS),
+// how a column's record is laid out in LDS, and which instruction multiplies; everything else (segments, chunks, accumulation
+// chains, branch-free screen, candidate queue, exact completion) is the one kernel below.
+struct FmtI8 {  // +-1 as int8: v_mfma_i32_32x32x32_i8 evaluates a 32-bit slice of 32 x 32 pairs; one fragment per hash dword
+    typedef v16i Acc;
+    typedef int Scalar;
+    typedef uint2 Lut;  // byte -> 8 int8
+    static constexpr int nfrag(int pw) { return pw; }
+    static constexpr int pitch(int pw) { return 2 * pw * 16 + 16; }  // [k-half h][dword kb][16 x i8] + pad (conflict-free b128, lane = column)
+    static constexpr int chunk(int pw) { return pw <= 4 ? 256 : 128; }
+    static constexpr int row_blocks(int pw) { return pw <= 4 ? 8 : 4; }  // A fragments: row_blocks * nfrag * 4 VGPRs
+    static constexpr int blocks_per_cu(int) { return 2; }
+    static __device__ __forceinline__ Lut lut_entry(uint32_t byte) { return expand_byte(byte); }
+    // fragment f of a row for k-half h: the 16 bits [32 f + 16 h, +16) of the row
+    static __device__ __forceinline__ v4i a_frag(const Lut *lut, const uint32_t *d, int f, int h)
+    {
+        const uint32_t hw = (d[f] >> (16 * h)) & 0xFFFFu;
+        const uint2 e0 = lut[hw & 0xFFu], e1 = lut[hw >> 8];
+        return v4i{(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
     }
-}
+    // packed dword kb of a column -> its two 16-byte records (one per k-half)
+    template <int PW>
+    static __device__ __forceinline__ void expand(const Lut *lut, uint8_t *col, uint32_t kb, uint32_t dw, bool live)
+    {
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const uint32_t hw = (dw >> (16 * hh)) & 0xFFFFu;
+            uint2 e0 = lut[hw & 0xFFu], e1 = lut[hw >> 8];
+            if (!live) e0 = e1 = make_uint2(0, 0);  // zero bytes: dot 0, never a candidate unless every pair is
+            *reinterpret_cast<uint4 *>(col + kb * 16 + hh * PW * 16) = make_uint4(e0.x, e0.y, e1.x, e1.y);
+        }
+    }
+    static __device__ __forceinline__ Acc zero() { return Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+    static __device__ __forceinline__ Acc mfma(v4i a, v4i b, Acc c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ Scalar max3(Scalar a, Scalar b, Scalar c) { return max3i(a, b, c); }
+    static __device__ __forceinline__ Scalar max2(Scalar a, Scalar b) { return max2i(a, b); }
+    static __device__ __forceinline__ Scalar thresh(int t) { return t; }
+};
 
+struct FmtFp4 {  // +-1 as e2m1 (0x2 / 0xA): v_mfma_scale_f32_32x32x64_f8f6f4 at unit scales evaluates a 64-bit slice; f32 accumulation exact
+    typedef v16f Acc;
+    typedef float Scalar;
+    typedef uint32_t Lut;  // byte -> 8 fp4 codes
+    static constexpr int nfrag(int pw) { return pw / 2; }
+    static constexpr int pitch(int pw) { return pw * 16 + 16; }  // [k-half h][slice][32 x fp4 = 16 B] + pad
+    // 128 columns at PW <= 4: with 256 the 54 KB of LDS per workgroup let only two of the three workgroups the register budget
+    // allows share a CU (measured: 23.1 -> 24.7 Tpairs/s)
+    static constexpr int chunk(int pw) { return pw <= 4 ? 128 : 256; }
+    static constexpr int row_blocks(int) { return 8; }
+    static constexpr int blocks_per_cu(int pw) { return pw <= 4 ? 3 : 2; }
+    static __device__ __forceinline__ Lut lut_entry(uint32_t byte)
+    {
+        uint32_t e = 0;
+        for (int i = 0; i < 8; i++) e |= (((byte >> i) & 1u) ? 0x2u : 0xAu) << (4 * i);
+        return e;
+    }
+    // fragment (slice) f of a row for k-half h: the 32 bits of dword 2 f + h
+    static __device__ __forceinline__ v4i a_frag(const Lut *lut, const uint32_t *d, int f, int h)
+    {
+        const uint32_t dw = h ? d[2 * f + 1] : d[2 * f];
+        return v4i{(int)lut[dw & 0xFFu], (int)lut[(dw >> 8) & 0xFFu], (int)lut[(dw >> 16) & 0xFFu], (int)lut[dw >> 24]};
+    }
+    // packed dword kb of a column -> the 16-byte record of slice kb / 2, k-half kb & 1
+    template <int PW>
+    static __device__ __forceinline__ void expand(const Lut *lut, uint8_t *col, uint32_t kb, uint32_t dw, bool live)
+    {
+        uint4 e = make_uint4(lut[dw & 0xFFu], lut[(dw >> 8) & 0xFFu], lut[(dw >> 16) & 0xFFu], lut[dw >> 24]);
+        if (!live) e = make_uint4(0, 0, 0, 0);  // fp4 zeros: dot 0, never a candidate unless every pair is
+        *reinterpret_cast<uint4 *>(col + ((kb & 1) * (PW / 2) + (kb >> 1)) * 16) = e;
+    }
+    static __device__ __forceinline__ Acc zero() { return Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+    static __device__ __forceinline__ Acc mfma(v4i a, v4i b, Acc c)
+    {  // cbsz = blgp = 4: fp4 e2m1; E8M0 scale 127 = 2^0
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0}, v8i{b[0], b[1], b[2], b[3], 0, 0, 0, 0}, c, 4,
+                                                               4, 0, 127, 0, 127);
+    }
+    static __device__ __forceinline__ Scalar max3(Scalar a, Scalar b, Scalar c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+    static __device__ __forceinline__ Scalar max2(Scalar a, Scalar b) { return __builtin_fmaxf(a, b); }
+    static __device__ __forceinline__ Scalar thresh(int t) { return (float)t; }
+};
 
 // Exact completion of one u64 pair (impl HammingHash for u64, hamminghash.rs:23-41): distance, i < j, find_groups reachability
 // over 8 chunks of 8 bits (first chunk with popcount <= tol; slot 0 = exact bucket, 1 + b = flip of bit b), append.
@@ -463,26 +350,23 @@ __device__ __forceinline__ void complete_pair_u64(const SweepArgs &a, unsigned l
     }
 }
 
-// FP4 (e2m1) formulation, same structure as the int8 kernel: +1 = 0x2, -1 = 0xA, one v_mfma_scale_f32_32x32x64_f8f6f4 (scales 1.0)
-// evaluates a 64-bit slice of 32 x 32 pairs; f32 accumulation of +-1 products is exact.  PW (even) = prefix dwords.
-__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-
-// U64: the hashes are 64-bit (stride 2 dwords, PW = 2: the whole hash is one MFMA slice) and pairs are completed by complete_pair_u64.
-template <int PW, bool U64 = false>
-__global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(SweepArgs a)
+// U64: the hashes are 64-bit (stride 2 dwords, PW = 2: the whole hash is one fp4 MFMA slice) and pairs are completed by complete_pair_u64.
+template <class F, int PW, bool U64 = false>
+__global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_kernel(SweepArgs a)
 {
-    constexpr int HS = U64 ? 2 : 8;          // dwords per hash
+    constexpr int HS = U64 ? 2 : 8;               // dwords per hash
+    constexpr int NF = F::nfrag(PW);              // MFMAs per 32 x 32 tile
+    constexpr int PITCH = F::pitch(PW);           // bytes per column record in LDS
+    constexpr int CHUNK = F::chunk(PW);           // columns expanded into LDS at a time (two buffers)
+    constexpr int QCAP = 128;                     // candidate queue per wave (entries of 8 bytes); overflow falls back to an exhaustive completion
+    constexpr int MF_RB = F::row_blocks(PW);      // 32-row blocks per wave and pass
+    constexpr int PASS_ROWS = 4 * 32 * MF_RB;     // rows one pass of the 4 waves covers; T_FILES / PASS_ROWS passes per tile
     static_assert(!U64 || PW == 2, "u64 hashes are swept at full width");
-    constexpr int NK = PW / 2;               // MFMAs (64-bit slices) per tile
-    constexpr int PITCH = PW * 16 + 16;      // bytes per column: [k-half h][slice][32 x fp4 = 16 B] + pad
-    // columns expanded into LDS at a time (two buffers).  128 at PW <= 4: with 256 the 54 KB of LDS per workgroup let only two of the
-    // three workgroups the register budget allows share a CU (measured: 23.1 -> 24.7 Tpairs/s)
-    constexpr int CHUNK = PW <= 4 ? 128 : 256;
-    constexpr int QCAP = 128;                // candidate queue per wave (entries of 8 bytes); overflow falls back to an exhaustive completion
-    constexpr int MF_RB = 8;                 // 32-row blocks per wave and pass (A fragments: MF_RB * NK * 4 VGPRs)
-    constexpr int PASS_ROWS = 4 * 32 * MF_RB; // rows one pass of the 4 waves covers; T_FILES / PASS_ROWS passes per tile
+    static_assert((CHUNK / 32) * (MF_RB / 2) <= 32, "candidate bitmap of a chunk is one dword");
+    typedef typename F::Acc Acc;
+    typedef typename F::Scalar Scalar;
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * CHUNK * PITCH];
-    __shared__ uint32_t s_lut[256];     // byte -> 8 fp4 codes
+    __shared__ typename F::Lut s_lut[256];
     __shared__ uint2 s_q[4][QCAP];      // one queue per wave: filled and drained by the same wave, no barrier needed
     __shared__ uint32_t s_qn[4];
 
@@ -497,17 +381,13 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
     const unsigned long long seg_cols = (unsigned long long)a.seg_tiles * T_FILES;
     const uint32_t ncols = (uint32_t)((a.n - col0) < seg_cols ? (a.n - col0) : seg_cols);  // <= 8192: queue entries keep 16 bits for it
 
-    {
-        uint32_t e = 0;
-        for (int i = 0; i < 8; i++) e |= (((threadIdx.x >> i) & 1u) ? 0x2u : 0xAu) << (4 * i);
-        s_lut[threadIdx.x] = e;
-    }
+    s_lut[threadIdx.x] = F::lut_entry(threadIdx.x);
     if (threadIdx.x < 4) s_qn[threadIdx.x] = 0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c32 = lane & 31, h = lane >> 5;
-    const float thresh_dot = (float)(32 * PW - 2 * (int)a.threshold);  // partial distance <= threshold  <=>  dot >= 32 PW - 2 threshold
+    const Scalar thresh_dot = F::thresh(32 * PW - 2 * (int)a.threshold);  // partial distance <= threshold  <=>  dot >= 32 PW - 2 threshold
     const uint32_t nv = a.n_variants;
 
     for (uint32_t vp = 0; vp < nv * (T_FILES / PASS_ROWS); vp++) {
@@ -519,8 +399,8 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
                 complete_pair(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, owner, col, v);
         };
         const uint32_t wrow = (vp % (T_FILES / PASS_ROWS)) * PASS_ROWS + wave * 32 * MF_RB;  // first tile row of this wave in this pass
-        // A fragments: row block rb, slice ks: this lane (row c32, half h) holds the 32 bits of dword 2 ks + h of its row
-        v8i A[MF_RB][NK];
+        // A fragments: this lane holds, for row block rb and fragment f, the operand bytes of row c32 for k-half h
+        v4i A[MF_RB][NF];
 #pragma unroll
         for (int rb = 0; rb < MF_RB; rb++) {
             const unsigned long long owner = row0 + wrow + 32ull * rb + c32;
@@ -538,10 +418,7 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
                 d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
             }
 #pragma unroll
-            for (int ks = 0; ks < NK; ks++) {
-                const uint32_t dw = h ? d[2 * ks + 1] : d[2 * ks];
-                A[rb][ks] = v8i{(int)s_lut[dw & 0xFFu], (int)s_lut[(dw >> 8) & 0xFFu], (int)s_lut[(dw >> 16) & 0xFFu], (int)s_lut[dw >> 24], 0, 0, 0, 0};
-            }
+            for (int f = 0; f < NF; f++) A[rb][f] = F::a_frag(s_lut, d, f, h);
         }
 
         // column chunks are double buffered: the packed dwords of chunk i + 1 are fetched into registers while chunk i
@@ -562,13 +439,7 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
                 const uint32_t t = threadIdx.x + q * MF_BLOCK;
                 if (t >= CHUNK * PW) continue;
                 const uint32_t col = t / PW, kb = t % PW;
-                const bool live = cbase + col < ncols;
-                // dword kb belongs to slice kb / 2, k-half kb & 1
-                uint8_t *dst = buf + col * PITCH + ((kb & 1) * NK + (kb >> 1)) * 16;
-                const uint32_t dw = pre[q];
-                uint4 e = make_uint4(s_lut[dw & 0xFFu], s_lut[(dw >> 8) & 0xFFu], s_lut[(dw >> 16) & 0xFFu], s_lut[dw >> 24]);
-                if (!live) e = make_uint4(0, 0, 0, 0);  // fp4 zeros: dot 0, never a candidate unless every pair is
-                *reinterpret_cast<uint4 *>(dst) = e;
+                F::template expand<PW>(s_lut, buf + col * PITCH, kb, pre[q], cbase + col < ncols);
             }
         };
         fetch(0);
@@ -586,42 +457,35 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
 #pragma unroll 1
             for (int cb = 0; cb < CHUNK / 32; cb++) {
                 if (cbase + cb * 32 >= ncols) break;
-                v8i B[NK];
-                const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * NK * 16;
+                v4i B[NF];
+                const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * NF * 16;
 #pragma unroll
-                for (int ks = 0; ks < NK; ks++) {
-                    const v4i t = *reinterpret_cast<const v4i *>(bp + ks * 16);
-                    B[ks] = v8i{t[0], t[1], t[2], t[3], 0, 0, 0, 0};
-                }
+                for (int f = 0; f < NF; f++) B[f] = *reinterpret_cast<const v4i *>(bp + f * 16);
                 // max of the 32 accumulators of the two tiles in 16 instructions: a tree of 15 three-input maxima and one two-input
                 // one (depth 4).  A linear chain of dependent VALU instructions issues at ~9 clk each from one wave
                 // (tools/valu_dep.hip), independent ones at ~5.6.
-                auto max32 = [&](const v16f &p, const v16f &q) {
-                    const auto t0 = max3f(p[0], p[1], p[2]), t1 = max3f(p[3], p[4], p[5]), t2 = max3f(p[6], p[7], p[8]);
-                    const auto t3 = max3f(p[9], p[10], p[11]), t4 = max3f(p[12], p[13], p[14]);
-                    const auto t5 = max3f(q[0], q[1], q[2]), t6 = max3f(q[3], q[4], q[5]), t7 = max3f(q[6], q[7], q[8]);
-                    const auto t8 = max3f(q[9], q[10], q[11]), t9 = max3f(q[12], q[13], q[14]);
-                    const auto u0 = max3f(t0, t1, t2), u1 = max3f(t3, t4, p[15]), u2 = max3f(t5, t6, t7), u3 = max3f(t8, t9, q[15]);
-                    return __builtin_fmaxf(max3f(u0, u1, u2), u3);
+                auto max32 = [&](const Acc &x, const Acc &y) {
+                    const Scalar t0 = F::max3(x[0], x[1], x[2]), t1 = F::max3(x[3], x[4], x[5]), t2 = F::max3(x[6], x[7], x[8]);
+                    const Scalar t3 = F::max3(x[9], x[10], x[11]), t4 = F::max3(x[12], x[13], x[14]);
+                    const Scalar t5 = F::max3(y[0], y[1], y[2]), t6 = F::max3(y[3], y[4], y[5]), t7 = F::max3(y[6], y[7], y[8]);
+                    const Scalar t8 = F::max3(y[9], y[10], y[11]), t9 = F::max3(y[12], y[13], y[14]);
+                    const Scalar u0 = F::max3(t0, t1, t2), u1 = F::max3(t3, t4, x[15]), u2 = F::max3(t5, t6, t7), u3 = F::max3(t8, t9, y[15]);
+                    return F::max2(F::max3(u0, u1, u2), u3);
                 };
                 // One test for the two tiles of a chain pair, and no branch: the lane only sets bit (cb, rb / 2) of its candidate
                 // bitmap of the chunk.  (A branch here, however rare, stalls this wave's MFMA issue and, through the chunk
                 // barriers, its three block mates: 8e6 queue pushes cost 10 ms at threshold 40.)
-                auto screen2 = [&](const v16f &a0, const v16f &a1, int rb) {
-                    cand |= (max32(a0, a1) >= thresh_dot) ? (1u << (cb * (MF_RB / 2) + rb / 2)) : 0u;
-                };
-                // two independent accumulation chains are interleaved (a dependent i8 MFMA issues every ~55 clk, an
-                // independent one every 32: tools/mfma_rate.hip)
+                // Two independent accumulation chains are interleaved (a dependent MFMA issues every ~55 clk, an independent one
+                // every 32: tools/mfma_rate.hip).
 #pragma unroll
                 for (int rb = 0; rb < MF_RB; rb += 2) {
-                    v16f acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    v16f acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    Acc acc0 = F::zero(), acc1 = F::zero();
 #pragma unroll
-                    for (int ks = 0; ks < NK; ks++) {  // cbsz = blgp = 4: fp4 e2m1; E8M0 scale 127 = 2^0
-                        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rb][ks], B[ks], acc0, 4, 4, 0, 127, 0, 127);
-                        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rb + 1][ks], B[ks], acc1, 4, 4, 0, 127, 0, 127);
+                    for (int f = 0; f < NF; f++) {
+                        acc0 = F::mfma(A[rb][f], B[f], acc0);
+                        acc1 = F::mfma(A[rb + 1][f], B[f], acc1);
                     }
-                    screen2(acc0, acc1, rb);
+                    cand |= (max32(acc0, acc1) >= thresh_dot) ? (1u << (cb * (MF_RB / 2) + rb / 2)) : 0u;
                 }
             }
 
@@ -680,9 +544,6 @@ __global__ void __launch_bounds__(MF_BLOCK, PW <= 4 ? 3 : 2) hamming_fp4_kernel(
         __syncthreads();  // the last chunk's buffers and queue are free before the next pass starts
     }
 }
-
-
-
 
 // ---------------------------------------------------------------------------------------------
 // 64-bit hashes (impl HammingHash for u64, hamminghash.rs:23-41): the same tiled sweep, 2 dwords per hash
@@ -817,22 +678,22 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
         const dim3 grid((unsigned)((mine - b0) < MAX_GRID ? (mine - b0) : MAX_GRID)), block(BLOCK), mblock(MF_BLOCK);
         if (use_mfma == 2) {
             if (pw == 4)
-                hipLaunchKernelGGL(hamming_fp4_kernel<4>, grid, mblock, 0, stream, a);
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtFp4, 4>), grid, mblock, 0, stream, a);
             else if (pw == 6)
-                hipLaunchKernelGGL(hamming_fp4_kernel<6>, grid, mblock, 0, stream, a);
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtFp4, 6>), grid, mblock, 0, stream, a);
             else
-                hipLaunchKernelGGL(hamming_fp4_kernel<8>, grid, mblock, 0, stream, a);
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtFp4, 8>), grid, mblock, 0, stream, a);
         } else if (use_mfma) {
             if (pw == 4)
-                hipLaunchKernelGGL(hamming_mfma_kernel<4>, grid, mblock, 0, stream, a);
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtI8, 4>), grid, mblock, 0, stream, a);
             else if (pw == 5)
-                hipLaunchKernelGGL(hamming_mfma_kernel<5>, grid, mblock, 0, stream, a);
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtI8, 5>), grid, mblock, 0, stream, a);
             else if (pw == 6)
-                hipLaunchKernelGGL(hamming_mfma_kernel<6>, grid, mblock, 0, stream, a);
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtI8, 6>), grid, mblock, 0, stream, a);
             else if (pw == 7)
-                hipLaunchKernelGGL(hamming_mfma_kernel<7>, grid, mblock, 0, stream, a);
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtI8, 7>), grid, mblock, 0, stream, a);
             else
-                hipLaunchKernelGGL(hamming_mfma_kernel<8>, grid, mblock, 0, stream, a);
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtI8, 8>), grid, mblock, 0, stream, a);
         } else {
             if (pw == 4)
                 hipLaunchKernelGGL(hamming_sweep_kernel<4>, grid, block, 0, stream, a);
@@ -881,7 +742,7 @@ int rph_launch_hamming64_sweep(const uint64_t *d_hashes, uint64_t n, uint32_t th
         const unsigned long long mine = (m.n_tile_pairs > part) ? (m.n_tile_pairs - part + nparts - 1) / nparts : 0;
         for (unsigned long long b0 = 0; b0 < mine; b0 += MAX_GRID) {
             m.block0 = b0;
-            hipLaunchKernelGGL((hamming_fp4_kernel<2, true>), dim3((unsigned)((mine - b0) < MAX_GRID ? (mine - b0) : MAX_GRID)), dim3(MF_BLOCK), 0,
+            hipLaunchKernelGGL((hamming_mfma_kernel<FmtFp4, 2, true>), dim3((unsigned)((mine - b0) < MAX_GRID ? (mine - b0) : MAX_GRID)), dim3(MF_BLOCK), 0,
                                stream, m);
             RPH_HIP_CHECK(hipGetLastError());
         }

@@ -14,7 +14,7 @@ a = parse(f'{R}/profiles/r01_pmc_strip64_raw.txt'); b = parse(f'{R}/profiles/r01
 def pick(d, sub):
     for k in d:
         if sub in k: return k, d[k]
-_, p64 = pick(a, 'pdq_fused512'); _, p128 = pick(b, 'pdq_fused512'); hk, hm = pick(a, 'hamming_fp4_kernel<4')
+_, p64 = pick(a, 'pdq_fused512'); _, p128 = pick(b, 'pdq_fused512'); hk, hm = pick(a, 'hamming_fp4_kernel<4') if pick(a, 'hamming_fp4_kernel<4') else pick(a, 'FmtFp4, 4')
 n = 30000
 out = ["rocprofv3 --pmc passes (tools/run_pmc.sh: one counter group per run, --kernel-trace only), command per pass:",
        "  python3 bench.py --steps 1 --warmup 0 --images 30000 --hashes 1000000 --no-cpu-baseline [--pdq-kernel 2]",
@@ -31,7 +31,7 @@ for name, p in (("pdq_fused512_kernel<Geo<64>> (default)", p64), ("pdq_fused512_
             f"  wave-cycles: SQ_WAVE_CYCLES {p['SQ_WAVE_CYCLES']:.3g}; executing VALU {p['SQ_ACTIVE_INST_VALU']/p['SQ_WAVE_CYCLES']*100:.0f} %, SQ_WAIT_INST_ANY {p['SQ_WAIT_INST_ANY']/p['SQ_WAVE_CYCLES']*100:.0f} % of which LDS {p['SQ_WAIT_INST_LDS']/p['SQ_WAVE_CYCLES']*100:.1f} %",
             f"  LDS: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = {p['SQ_LDS_BANK_CONFLICT']/p['SQ_LDS_IDX_ACTIVE']*100:.0f} %", ""]
 nd = int(re.search(r'\((\d+) dispatches\)', hk).group(1))
-out += [f"hamming_fp4_kernel<4> (1M hashes, threshold 32; {nd} dispatches over the 7 passes: warm-up, the timed launch, and the 500k-file reference case in each)",
+out += [f"fp4 MFMA sweep, PW = 4 (1M hashes, threshold 32; {nd} dispatches over the 7 passes: warm-up, the timed launch, and the 500k-file reference case in each)",
         f"  SQ_INSTS_MFMA {hm.get('SQ_INSTS_MFMA', 0):.4g}, SQ_INSTS_VALU {hm['SQ_INSTS_VALU']:.4g}",
         f"  SQ_VALU_MFMA_BUSY_CYCLES {hm['SQ_VALU_MFMA_BUSY_CYCLES']:.4g} / (GRBM_GUI_ACTIVE {hm['GRBM_GUI_ACTIVE']:.4g} summed over 8 XCDs / 8 x 1024 SIMDs) = {hm['SQ_VALU_MFMA_BUSY_CYCLES']/(hm['GRBM_GUI_ACTIVE']/8*1024)*100:.0f} % matrix-pipe busy",
         f"  wave-cycles: executing VALU {hm['SQ_ACTIVE_INST_VALU']/hm['SQ_WAVE_CYCLES']*100:.0f} %, SQ_WAIT_INST_ANY {hm['SQ_WAIT_INST_ANY']/hm['SQ_WAVE_CYCLES']*100:.0f} % (LDS {hm['SQ_WAIT_INST_LDS']/hm['SQ_WAVE_CYCLES']*100:.1f} %)",

@@ -18,4 +18,4 @@ WRITE_SIZE
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE
 LIST
-python3 $R/tools/pmc_summary.py $OUT pdq_fused512 hamming_mfma hamming_fp4
+python3 $R/tools/pmc_summary.py $OUT pdq_fused512 hamming_mfma
