@@ -4,17 +4,25 @@
 A "step" is one pass of the hot path over one resident batch:
   phase A (-> `value`): PDQ-hash `--images` synthetic 512x512 RGB8 images per GPU (BASELINE config 2:
            100 000 images on 1 GPU; weak scaling: every rank hashes its own 100 000);
+  phase C (-> `e2e`):   BASELINE config 4 as ONE timed region over the same resident images: hash (hash + quality +
+           8 dihedral hashes) -> RCCL all-gather of the per-file hash blocks -> every rank sweeps its share of the block
+           pairs with the production rule of group_files_generic (8 variants, low-quality rule) -> edges to rank 0 ->
+           union-find; the near-duplicate pairs of the synthetic sequence (k % 1000 == 999) must come out as groups;
   phase B (-> `hamming`): all-pairs 256-bit Hamming sweep, threshold 32, over 1M*sqrt(N) synthetic
            hashes (BASELINE config 3 at N=1; per-GPU pair count fixed as N grows): every rank generates
            its shard, one RCCL all-gather of the hash shards, then each rank sweeps its share of the tile pairs.
-Inputs are generated on the device and resident in HBM before the timed region.
-One JSON line on rank 0.  Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under
-torch.distributed.run (one process per GPU).
+Inputs are generated on the device and resident in HBM before the timed regions.
+One JSON line on rank 0.  Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either start it under
+torch.distributed.run (one process per GPU), or just run `python bench.py --gpus N`: with WORLD_SIZE unset it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child BEFORE anything touches the GPU and exits
+with the child's status.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,21 +34,35 @@ ALGO_BYTES_PER_IMAGE = IMG_BYTES + 32          # 786 432 B read + 3
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6e12 (full-rate VOP2 ops only)
 MFMA_I8_OPS_PER_S = 256 * 4 * (32 * 32 * 32 * 2) / 32 * 2.4e9  # v_mfma_i32_32x32x32_i8: 65 536 ops / 32 clk / SIMD = 5.03e15
+HAMMING_HBM_BYTES_PER_PAIR = 64.0 / 1024       # 2 T 32 B / T^2 with T = 1024-hash tiles
 
 
-def usable_cores():
-    """threads for the CPU baseline: the affinity mask / cgroup quota, capped at the GPU box's per-GPU CPU share (16)"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def cpu_inventory():
+    """what the host offers and what the CPU baseline uses (print nproc and hardware_concurrency)"""
+    nproc = os.cpu_count() or 1                      # = std::thread::hardware_concurrency()
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc   # = `nproc`
+    quota = None
     try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(period)))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, int(os.environ.get("RPH_CPU_THREADS", "16"))))
+    threads = min(affinity, quota) if quota else affinity
+    if os.environ.get("RPH_CPU_THREADS"):
+        threads = int(os.environ["RPH_CPU_THREADS"])
+    return {"hardware_concurrency": nproc, "nproc_affinity": affinity, "cgroup_cpu_quota": quota, "threads_used": max(1, threads)}
 
 
-def main():
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -54,17 +76,48 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal: ranks may "
                     "share one GPU, collectives are staged through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline leg")
-    args = ap.parse_args()
+    ap.add_argument("--no-reference-cases", action="store_true", help="skip the reference's own published cases (keeps a profile of the default "
+                    "workloads free of other launches of the same kernels)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip phase C (config 4 as one timed region)")
+    ap.add_argument("--e2e-steps", type=int, default=3)
+    ap.add_argument("--only", default="", help="comma list of phases to run: pdq, e2e, hamming (default: all)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget per cpu_baseline leg")
+    return ap.parse_args()
 
-    import numpy as np
-    import torch
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # self-launch: one process per GPU under torch.distributed.run.  Nothing in THIS process has touched the GPU (torch is
+        # not even imported yet), and the parent never execs: it waits for the child and exits with its status.
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    phases = set(p for p in args.only.split(",") if p) or {"pdq", "e2e", "hamming"}
+    if args.no_e2e:
+        phases.discard("e2e")
+
+    # The CPU oracle (the checker and the cpu_baseline leg) is loaded BEFORE the GPU is initialised and is never built from
+    # here: a `make` child of a process that holds the GPU (or runs under a profiler's preload) would be a forbidden exec.
+    oracle = None
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if want_cpu:
+        os.environ["RPH_ORACLE_NO_BUILD"] = "1"
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle as oracle_mod
+
+        oracle_mod.lib()  # raises if __graft_entry__.build() has not produced oracle/liboracle_ref.so
+        oracle = oracle_mod
+
+    import numpy as np
+    import torch
+
     if args.backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsal on fewer GPUs than ranks
     torch.cuda.set_device(local_rank)
@@ -78,7 +131,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from rupphash_amd import EDGE_DTYPE, Engine
+    from rupphash_amd import Engine
+    from rupphash_amd import dist as D
 
     eng = Engine(local_rank)
     eng.set_pdq_kernel(args.pdq_kernel)
@@ -89,6 +143,7 @@ def main():
     ts = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(ts)
     stream = ts.cuda_stream
+    coll_dev = dev if args.backend == "nccl" else "cpu"
 
     def barrier_sync():
         torch.cuda.synchronize()
@@ -99,9 +154,25 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def sum_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(t)
+        return int(t.item())
+
+    valid = True
+    problems = []
+    result = {
+        "metric": "pdq_hashes_per_sec_512x512_rgb", "value": None, "unit": "hashes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ranks_in_collective": dist.get_world_size() if dist is not None else 1,
+        "backend": (str(dist.get_backend()) + (" (RCCL)" if args.backend == "nccl" else "")) if dist is not None else "none (1 process)",
+    }
 
     # ------------------------------------------------------------------ phase A: PDQ hashing
     n_img = args.images
@@ -114,250 +185,321 @@ def main():
     def pdq_step():
         eng.pdq_hash_batch_dev(imgs.data_ptr(), n_img, 512, 512, 3, hashes.data_ptr(), stream=stream)
 
-    for _ in range(args.warmup):
-        pdq_step()
-    ev = [(eng.event(), eng.event()) for _ in range(args.steps)]
-    barrier_sync()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        eng.event_record(ev[s][0], stream)
-        pdq_step()
-        eng.event_record(ev[s][1], stream)
-    barrier_sync()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    kernel_ms = [eng.event_elapsed_ms(a, b) for a, b in ev]
-    for a, b in ev:
-        eng.event_destroy(a)
-        eng.event_destroy(b)
-    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-    value = world * n_img * args.steps / elapsed
-    achieved_gbs = ALGO_BYTES_PER_IMAGE * n_img / (avg_kernel_ms * 1e-3) / 1e9
-    # what a pure read stream over the same resident images gets on this GPU (untimed part of the job; rank 0's figure is reported)
-    read_gbs = None
-    if rank == 0:
-        eng.read_stream_dev(imgs.data_ptr(), n_img * IMG_BYTES, stream=stream)
-        ra, rb = eng.event(), eng.event()
-        eng.event_record(ra, stream)
-        for _ in range(3):
+    pdq_sample = None
+    if "pdq" in phases:
+        for _ in range(args.warmup):
+            pdq_step()
+        ev = [(eng.event(), eng.event()) for _ in range(args.steps)]
+        barrier_sync()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            eng.event_record(ev[s][0], stream)
+            pdq_step()
+            eng.event_record(ev[s][1], stream)
+        barrier_sync()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        kernel_ms = [eng.event_elapsed_ms(a, b) for a, b in ev]
+        for a, b in ev:
+            eng.event_destroy(a)
+            eng.event_destroy(b)
+        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        value = world * n_img * args.steps / elapsed
+        achieved_gbs = ALGO_BYTES_PER_IMAGE * n_img / (avg_kernel_ms * 1e-3) / 1e9
+        # what a pure read stream over the same resident images gets on this GPU (untimed part of the job; rank 0's figure is reported)
+        read_gbs = None
+        if rank == 0:
             eng.read_stream_dev(imgs.data_ptr(), n_img * IMG_BYTES, stream=stream)
-        eng.event_record(rb, stream)
-        torch.cuda.synchronize()
-        read_gbs = 3.0 * n_img * IMG_BYTES / (eng.event_elapsed_ms(ra, rb) * 1e-3) / 1e9
-        eng.event_destroy(ra)
-        eng.event_destroy(rb)
-    hash_checksum = int(hashes.to(torch.int64).sum().item())
-    pdq_sample = hashes[:64].cpu().numpy()
-    img_sample = imgs[:64].cpu().numpy().reshape(64, 512, 512, 3)
+            ra, rb = eng.event(), eng.event()
+            eng.event_record(ra, stream)
+            for _ in range(3):
+                eng.read_stream_dev(imgs.data_ptr(), n_img * IMG_BYTES, stream=stream)
+            eng.event_record(rb, stream)
+            torch.cuda.synchronize()
+            read_gbs = 3.0 * n_img * IMG_BYTES / (eng.event_elapsed_ms(ra, rb) * 1e-3) / 1e9
+            eng.event_destroy(ra)
+            eng.event_destroy(rb)
+        hash_checksum = int(hashes.to(torch.int64).sum().item())
+        pdq_sample = hashes[:64].cpu().numpy()
 
-    # HBM traffic per launch: rocprofv3 cannot run inside this process, so the figure is the PMC measurement of this same kernel
-    # committed under profiles/ (FETCH_SIZE, corrected as MI355X_MICROARCH.md prescribes), scaled to this launch's image count
-    traffic_bytes, traffic_source = None, None
-    tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pdq_traffic.json")
-    if os.path.exists(tfile):
-        with open(tfile) as f:
-            tj = json.load(f)
-        per_image = tj.get({0: "generic", 1: "fused512_strip64", 2: "fused512_strip128"}[args.pdq_kernel])
-        if per_image:
-            traffic_bytes = per_image * n_img
-            traffic_source = tj.get("source")
+        # L2 -> fabric read bytes per launch: rocprofv3 cannot run inside this process, so the figure is the PMC measurement of this
+        # same kernel committed under profiles/ (FETCH_SIZE, corrected as MI355X_MICROARCH.md prescribes and calibrated on the read
+        # stream kernel of the same run), scaled to this launch's image count.  The counter sits on the L2's memory side and counts
+        # Infinity-Cache hits too, so it can exceed what HBM itself delivered (and the rate of a pure HBM read stream).
+        traffic_bytes, traffic_source = None, None
+        tfile = os.path.join(ROOT, "profiles", "pdq_traffic.json")
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                tj = json.load(f)
+            per_image = tj.get({0: "generic", 1: "fused512_strip64", 2: "fused512_strip128"}[args.pdq_kernel])
+            if per_image:
+                traffic_bytes = per_image * n_img
+                traffic_source = tj.get("source")
+        result.update({
+            "value": value, "ms_per_step": elapsed / args.steps * 1e3,
+            "config": {"workload": f"batch PDQ hash of {n_img} synthetic 512x512 RGB8 images per GPU, resident in HBM "
+                                   "(BASELINE config 2), hash-only output",
+                       "images_per_gpu": n_img, "image": "512x512x3 u8",
+                       "pdq_kernel": {0: "generic", 1: "fused512/strip64", 2: "fused512/strip128"}[args.pdq_kernel], "hash_checksum": hash_checksum},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic_bytes, "traffic_source": traffic_source,
+                         "traffic_counts": "L2->fabric read bytes (Infinity-Cache hits included)",
+                         "kernel": "pdq_fused512_kernel" if args.pdq_kernel else "generic multi-pass", "kernel_ms": avg_kernel_ms,
+                         "algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_IMAGE * n_img,
+                         "measured_read_stream_gbs": read_gbs, "frac_of_measured_read_stream": (achieved_gbs / read_gbs) if read_gbs else None},
+        })
+
+    # ------------------------------------------------------------------ phase C: config 4 as one timed region
+    if "e2e" in phases:
+        n_total = n_img * world
+        e2e_steps = max(1, args.e2e_steps)
+        timings = {}
+        groups, info = D.hash_and_group_device(eng, imgs, n_total, args.threshold, dist, variants=True)  # warm-up (allocations, RCCL channels)
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(e2e_steps):
+            groups, info = D.hash_and_group_device(eng, imgs, n_total, args.threshold, dist, variants=True, timings=timings)
+        barrier_sync()
+        e2e_s = max_over_ranks(time.perf_counter() - t0) / e2e_steps
+        if rank == 0:
+            # image k of the global sequence with k % 1000 == 999 shares its block colours with image k - 1
+            want_pairs = [[k - 1, k] for k in range(999, n_total, 1000)]
+            gset = {tuple(g) for g in groups}
+            missing = [p for p in want_pairs if tuple(p) not in gset]
+            ok = not missing and len(groups) == len(want_pairs)
+            if not ok:
+                valid = False
+                problems.append(f"e2e: {len(groups)} groups, {len(missing)} of {len(want_pairs)} near-duplicate pairs missing")
+            result["e2e"] = {
+                "workload": f"{n_total} synthetic 512x512 RGB8 images resident in HBM ({n_img} per GPU) -> PDQ hash + quality + 8 dihedral hashes -> "
+                            "all-gather of the per-file hash blocks -> variant sweep (group_files_generic rule) -> edges to rank 0 -> union-find "
+                            "(BASELINE config 4; 1M images at 8 GPUs with --images 125000)",
+                "seconds_per_run": e2e_s, "images_per_s": n_total / e2e_s, "runs": e2e_steps, "similarity": args.threshold,
+                "groups": len(groups), "near_duplicate_pairs_expected": len(want_pairs), "near_duplicate_pairs_found": len(want_pairs) - len(missing),
+                "comparison_count": info["edges_total"], "ranks_in_collective": info["ranks_in_collective"],
+                "hash_and_exchange_s_rank0": timings.get("hash_and_exchange_s"), "all_pairs_evaluated": n_total * (n_total - 1) // 2 * 8,
+                "exchange": ("RCCL all-gather of 8 x 32 B per file + 1 B flags" if args.backend == "nccl" else "gloo all-gather (host staged)") if world > 1 else "none (1 GPU)",
+                "valid": ok}
+
+    img_sample_dev = imgs  # kept for the CPU baseline (same images)
 
     # ------------------------------------------------------------------ phase B: Hamming sweep
-    del imgs
-    torch.cuda.empty_cache()
-    n_h = int(round(args.hashes * math.sqrt(world) / (1024 * world))) * 1024 * world if args.hashes >= 1024 * world else args.hashes
-    shard = n_h // world
-    n_clusters = min(1000, max(0, n_h // 5 - 1))
-    all_h = torch.empty((n_h, 32), dtype=torch.uint8, device=dev)
-    mine = all_h[rank * shard:(rank + 1) * shard]
-    cap = 1 << 20
-    d_edges = torch.empty((cap, 12), dtype=torch.uint8, device=dev)
-    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
-    h_steps = args.hamming_steps or args.steps
+    if "hamming" in phases:
+        n_h = int(round(args.hashes * math.sqrt(world) / (1024 * world))) * 1024 * world if args.hashes >= 1024 * world else args.hashes
+        shard = n_h // world
+        n_clusters = min(1000, max(0, n_h // 5 - 1))
+        all_h = torch.empty((n_h, 32), dtype=torch.uint8, device=dev)
+        mine = all_h[rank * shard:(rank + 1) * shard]
+        cap = 1 << 20
+        d_edges = torch.empty((cap, 12), dtype=torch.uint8, device=dev)
+        d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        h_steps = args.hamming_steps or args.steps
+        gather_ev = []
 
-    def hamming_step():
-        # exchange step: every rank contributes its shard of hashes (in a real scan: the hashes it just computed)
-        eng.synth_hashes_dev(mine.data_ptr(), rank * shard, shard, n_h, n_clusters=n_clusters, stream=stream)
-        if dist is not None:
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(all_h, mine)  # the one exchange step of the path: RCCL all-gather of hash shards
-            else:
-                host = torch.empty((n_h, 32), dtype=torch.uint8)
-                dist.all_gather_into_tensor(host, mine.cpu())
-                all_h.copy_(host)
-        d_count.zero_()
-        eng.hamming_all_pairs_dev(all_h.data_ptr(), n_h, args.threshold, d_edges.data_ptr(), cap, d_count.data_ptr(),
-                                  part=rank, nparts=world, stream=stream)
+        def hamming_step(timed=False):
+            # exchange step: every rank contributes its shard of hashes (in a real scan: the hashes it just computed)
+            eng.synth_hashes_dev(mine.data_ptr(), rank * shard, shard, n_h, n_clusters=n_clusters, stream=stream)
+            if dist is not None:
+                if timed:
+                    ea, eb = eng.event(), eng.event()
+                    eng.event_record(ea, stream)
+                if args.backend == "nccl":
+                    dist.all_gather_into_tensor(all_h, mine)  # the one exchange step of the path: RCCL all-gather of hash shards
+                else:
+                    host = torch.empty((n_h, 32), dtype=torch.uint8)
+                    dist.all_gather_into_tensor(host, mine.cpu())
+                    all_h.copy_(host)
+                if timed:
+                    eng.event_record(eb, stream)
+                    gather_ev.append((ea, eb))
+            d_count.zero_()
+            eng.hamming_all_pairs_dev(all_h.data_ptr(), n_h, args.threshold, d_edges.data_ptr(), cap, d_count.data_ptr(),
+                                      part=rank, nparts=world, stream=stream)
 
-    for _ in range(max(1, min(args.warmup, 1))):
-        hamming_step()
-    hev = [(eng.event(), eng.event()) for _ in range(h_steps)]
-    barrier_sync()
-    t0 = time.perf_counter()
-    for s in range(h_steps):
-        eng.event_record(hev[s][0], stream)
-        hamming_step()
-        eng.event_record(hev[s][1], stream)
-    barrier_sync()
-    h_elapsed = max_over_ranks(time.perf_counter() - t0)
-    h_kernel_ms = sum(eng.event_elapsed_ms(a, b) for a, b in hev) / h_steps
-    n_pairs = n_h * (n_h - 1) // 2
-    gpairs = n_pairs * h_steps / h_elapsed / 1e9
-    n_edges_local = int(d_count.item())
-    n_edges = n_edges_local
-    if dist is not None:
-        t = torch.tensor([n_edges_local], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t)
-        n_edges = int(t.item())
-    expected_edges = n_clusters * 10 + (1 if n_h >= 10 else 0)
-    pw = eng.L.rph_hamming_prefix_dwords(args.threshold, args.hamming_kernel)  # prefix dwords the fast path examines
-    pairs_per_s_rank = (n_pairs / world) / (h_kernel_ms * 1e-3)
-    if args.hamming_kernel == 2:
-        # fp4 MFMA fast path: one v_mfma_scale_f32_32x32x64_f8f6f4 (131 072 fp4 ops) per 64-bit slice of 1024 pairs -> 64 * PW ops per pair,
-        # against the dense fp4 peak (2 x the fp8 / int8 peak)
-        h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": 2 * MFMA_I8_OPS_PER_S / 1e12, "unit": "TOP/s (fp4)",
-                  "frac": pairs_per_s_rank * 64 * pw / (2 * MFMA_I8_OPS_PER_S), "int8_equivalent_ops_per_pair": 64 * pw, "prefix_dwords": pw, "hbm_bytes_per_pair": 64.0 / 1024,
-                  "kernel_ms": h_kernel_ms, "kernel": "hamming_mfma_kernel<FmtFp4>"}
-    elif args.hamming_kernel == 1:
-        # int8 MFMA fast path: one v_mfma_i32_32x32x32_i8 (65 536 int8 ops) per 32-bit slice of 1024 pairs -> 64 * PW ops per pair
-        h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": MFMA_I8_OPS_PER_S / 1e12,
-                  "unit": "TOP/s (int8)", "frac": pairs_per_s_rank * 64 * pw / MFMA_I8_OPS_PER_S, "prefix_dwords": pw,
-                  "int8_ops_per_pair": 64 * pw, "hbm_bytes_per_pair": 64.0 / 1024, "kernel_ms": h_kernel_ms, "kernel": "hamming_mfma_kernel<FmtI8>"}
-    else:
-        lane_ops = 2 * pw * pairs_per_s_rank  # executed xor + bcnt lane-ops/s on this rank
-        h_roof = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12, "unit": "Tlane-op/s",
-                  "frac": lane_ops / VALU_LANE_OPS_PER_S, "prefix_dwords": pw, "lane_ops_per_pair": 2 * pw,
-                  "hbm_bytes_per_pair": 64.0 / 1024, "kernel_ms": h_kernel_ms, "kernel": "hamming_sweep_kernel",
-                  "note": "v_bcnt_u32_b32 is a half-rate op on gfx950 (tools/valu_rate.hip): the xor+bcnt bound is 6 clk per dword per wave"}
-
-    result = {
-        "metric": "pdq_hashes_per_sec_512x512_rgb",
-        "value": value,
-        "unit": "hashes/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": f"batch PDQ hash of {n_img} synthetic 512x512 RGB8 images per GPU, resident in HBM "
-                               "(BASELINE config 2), hash-only output",
-                   "images_per_gpu": n_img, "image": "512x512x3 u8", "pdq_kernel": {0: "generic", 1: "fused512/strip64", 2: "fused512/strip128"}[args.pdq_kernel],
-                   "hash_checksum": hash_checksum},
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic_bytes,
-                     "traffic_source": traffic_source,
-                     "kernel_ms": avg_kernel_ms, "algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE,
-                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_IMAGE * n_img,
-                     "measured_read_stream_gbs": read_gbs,
-                     "frac_of_measured_read_stream": (achieved_gbs / read_gbs) if read_gbs else None},
-        "hamming": {"metric": "hamming256_pair_comparisons_per_sec", "value": gpairs, "unit": "Gpairs/s",
-                    "n_hashes": n_h, "threshold": args.threshold, "steps": h_steps, "ms_per_step": h_elapsed / h_steps * 1e3,
-                    "scaling": "weak (pairs per GPU fixed: n = 1M*sqrt(N))", "edges_found": n_edges,
-                    "edges_expected": expected_edges,
-                    "exchange": "RCCL all-gather of hash shards" if world > 1 else "none (1 GPU)",
-                    "roofline": h_roof},
-    }
+        for _ in range(max(1, min(args.warmup, 1))):
+            hamming_step()
+        hev = [(eng.event(), eng.event()) for _ in range(h_steps)]
+        barrier_sync()
+        t0 = time.perf_counter()
+        for s in range(h_steps):
+            eng.event_record(hev[s][0], stream)
+            hamming_step(timed=True)
+            eng.event_record(hev[s][1], stream)
+        barrier_sync()
+        h_elapsed = max_over_ranks(time.perf_counter() - t0)
+        h_step_ms = sum(eng.event_elapsed_ms(a, b) for a, b in hev) / h_steps
+        gather_ms = (sum(eng.event_elapsed_ms(a, b) for a, b in gather_ev) / len(gather_ev)) if gather_ev else 0.0
+        h_kernel_ms = h_step_ms - gather_ms  # the sweep (+ the shard generator, ~0.01 ms) without the exchange
+        n_pairs = n_h * (n_h - 1) // 2
+        gpairs = n_pairs * h_steps / h_elapsed / 1e9
+        n_edges_local = int(d_count.item())
+        n_edges = sum_over_ranks(n_edges_local)
+        expected_edges = n_clusters * 10 + (1 if n_h >= 10 else 0)
+        h_ok = n_edges_local <= cap and (args.threshold != 32 or n_edges == expected_edges)
+        if not h_ok:
+            valid = False
+            problems.append(f"hamming: {n_edges} edges found, {expected_edges} expected (local {n_edges_local}, cap {cap})")
+        pw = eng.L.rph_hamming_prefix_dwords(args.threshold, args.hamming_kernel)  # prefix dwords the fast path examines
+        pairs_per_s_rank = (n_pairs / world) / (h_kernel_ms * 1e-3)
+        hbm = {"hbm_bytes_per_pair": HAMMING_HBM_BYTES_PER_PAIR,
+               "achieved_hbm_gbs": pairs_per_s_rank * HAMMING_HBM_BYTES_PER_PAIR / 1e9,
+               "achieved_hbm_frac_of_peak": pairs_per_s_rank * HAMMING_HBM_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS,
+               "hbm_note": "algorithmic tile bytes (64/T B per pair, T = 1024) / sweep time: far below peak by design -- the tiles are "
+                           "reused from LDS/registers; the binding roof is the matrix pipe"}
+        if args.hamming_kernel == 2:
+            # fp4 MFMA fast path: one v_mfma_scale_f32_32x32x64_f8f6f4 (131 072 fp4 ops) per 64-bit slice of 1024 pairs -> 64 * PW ops per pair,
+            # against the dense fp4 peak (2 x the fp8 / int8 peak)
+            h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": 2 * MFMA_I8_OPS_PER_S / 1e12, "unit": "TOP/s (fp4)",
+                      "frac": pairs_per_s_rank * 64 * pw / (2 * MFMA_I8_OPS_PER_S), "int8_equivalent_ops_per_pair": 64 * pw, "prefix_dwords": pw,
+                      "kernel_ms": h_kernel_ms, "kernel": "hamming_mfma_kernel<FmtFp4>"}
+        elif args.hamming_kernel == 1:
+            # int8 MFMA fast path: one v_mfma_i32_32x32x32_i8 (65 536 int8 ops) per 32-bit slice of 1024 pairs -> 64 * PW ops per pair
+            h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": MFMA_I8_OPS_PER_S / 1e12,
+                      "unit": "TOP/s (int8)", "frac": pairs_per_s_rank * 64 * pw / MFMA_I8_OPS_PER_S, "prefix_dwords": pw,
+                      "int8_ops_per_pair": 64 * pw, "kernel_ms": h_kernel_ms, "kernel": "hamming_mfma_kernel<FmtI8>"}
+        else:
+            lane_ops = 2 * pw * pairs_per_s_rank  # executed xor + bcnt lane-ops/s on this rank
+            h_roof = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12, "unit": "Tlane-op/s",
+                      "frac": lane_ops / VALU_LANE_OPS_PER_S, "prefix_dwords": pw, "lane_ops_per_pair": 2 * pw,
+                      "kernel_ms": h_kernel_ms, "kernel": "hamming_sweep_kernel",
+                      "note": "v_bcnt_u32_b32 is a half-rate op on gfx950 (tools/valu_rate.hip): the xor+bcnt bound is 6 clk per dword per wave"}
+        h_roof.update(hbm)
+        result["hamming"] = {"metric": "hamming256_pair_comparisons_per_sec", "value": gpairs, "unit": "Gpairs/s",
+                             "n_hashes": n_h, "threshold": args.threshold, "steps": h_steps, "ms_per_step": h_elapsed / h_steps * 1e3,
+                             "scaling": "weak (pairs per GPU fixed: n = 1M*sqrt(N))", "edges_found": n_edges, "edges_expected": expected_edges,
+                             "edge_capacity": cap, "valid": h_ok,
+                             "exchange": "RCCL all-gather of hash shards" if world > 1 else "none (1 GPU)",
+                             "allgather_ms": gather_ms, "allgather_bytes_per_rank": shard * 32,
+                             "roofline": h_roof}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle
-
-        cores = usable_cores()
-        # PDQ: the oracle on the first images of the same synthetic sequence, one image per task over all cores
-        t_pilot, hp, _ = oracle.bench_pdq(img_sample[:cores], cores)
-        per_img = max(t_pilot / cores, 1e-4)
-        n_cpu = int(min(max(args.cpu_seconds / per_img, cores), 4096))
-        cpu_imgs = img_sample if n_cpu <= 64 else oracle.synth_images(0, n_cpu)
-        cpu_imgs = cpu_imgs[:n_cpu]
-        secs, cpu_hashes, _ = oracle.bench_pdq(cpu_imgs, cores)
-        parity = bool(np.array_equal(cpu_hashes[:min(n_cpu, 64)], pdq_sample[:min(n_cpu, 64)]))
-        result["cpu_baseline"] = {"value": n_cpu / secs, "unit": "hashes/s", "cores": cores, "kind": "port",
-                                  "sample": f"{n_cpu} of the same synthetic 512x512 RGB8 images, C oracle, {cores} threads",
-                                  "gpu_hashes_equal_cpu_hashes_on_sample": parity}
-        # Hamming: brute-force XOR-popcount on a 64k subset (apples to apples), and the reference's own
-        # algorithm (MIH find_groups) on a timed query sample of the full 1M set
-        sub = all_h[:65536].cpu().numpy()
-        bsecs, _ = oracle.bench_all_pairs256(sub, args.threshold, cores)
-        full = all_h.cpu().numpy()
-        q_pilot = 20000
-        times, _ = oracle.bench_find_groups(oracle.KIND_PDQ, full, args.threshold, cores, q_limit=q_pilot)
-        q_rate = q_pilot / max(times[1], 1e-6)
-        result["hamming"]["cpu_baseline"] = {
-            "value": (65536 * 65535 / 2) / bsecs / 1e9, "unit": "Gpairs/s", "cores": cores, "kind": "port",
-            "sample": "brute-force XOR-popcount over all pairs of the first 65 536 hashes",
-            "mih_find_groups": {"index_build_s": times[0], "queries_per_s": q_rate,
-                                "extrapolated_s_for_all_queries": n_h / q_rate,
-                                "sample": f"MIHIndex::new on all {n_h} hashes + the first {q_pilot} queries of find_groups "
-                                          f"(max_dist {args.threshold}), {cores} threads"}}
+    if want_cpu:
+        inv = cpu_inventory()
+        cores = inv["threads_used"]
+        if "pdq" in phases:
+            # PDQ: the oracle on the first images of the same synthetic sequence (downloaded from the GPU: the generators are
+            # bit-identical, tests/test_gpu_parity.py), one image per task over all cores; >= 10 000 images in chunks of 2 048
+            chunk = 2048
+            first = img_sample_dev[:min(chunk, n_img)].cpu().numpy().reshape(-1, 512, 512, 3)
+            t_pilot, _, _ = oracle.bench_pdq(first[:cores], cores)
+            per_img = max(t_pilot / cores, 1e-5)
+            n_cpu = int(min(max(args.cpu_seconds / per_img, 10_000), 30_000, n_img))
+            secs, done, parity = 0.0, 0, True
+            while done < n_cpu:
+                m = min(chunk, n_cpu - done)
+                host = first[:m] if done == 0 else img_sample_dev[done:done + m].cpu().numpy().reshape(-1, 512, 512, 3)
+                s, cpu_hashes, _ = oracle.bench_pdq(host, cores)
+                secs += s
+                if done == 0 and pdq_sample is not None:
+                    parity = bool(np.array_equal(cpu_hashes[:64], pdq_sample[:min(m, 64)]))
+                done += m
+            if not parity:
+                valid = False
+                problems.append("pdq: GPU hashes differ from the CPU oracle on the sample")
+            result["cpu_baseline"] = {"value": n_cpu / secs, "unit": "hashes/s", "cores": cores, "kind": "port",
+                                      "sample": f"{n_cpu} of the same synthetic 512x512 RGB8 images, C oracle, {cores} threads ({secs:.1f} s)",
+                                      "host": inv, "gpu_hashes_equal_cpu_hashes_on_sample": parity}
+        if "hamming" in phases:
+            # Hamming: brute-force XOR-popcount on a 64k subset (apples to apples), and the reference's own
+            # algorithm (MIH find_groups) on a timed query sample of the full 1M set
+            sub = all_h[:65536].cpu().numpy()
+            bsecs, _ = oracle.bench_all_pairs256(sub, args.threshold, cores)
+            full = all_h.cpu().numpy()
+            q_pilot = 20000
+            times, _ = oracle.bench_find_groups(oracle.KIND_PDQ, full, args.threshold, cores, q_limit=q_pilot)
+            q_rate = q_pilot / max(times[1], 1e-6)
+            result["hamming"]["cpu_baseline"] = {
+                "value": (65536 * 65535 / 2) / bsecs / 1e9, "unit": "Gpairs/s", "cores": cores, "kind": "port", "host": inv,
+                "sample": "brute-force XOR-popcount over all pairs of the first 65 536 hashes",
+                "mih_find_groups": {"index_build_s": times[0], "queries_per_s": q_rate,
+                                    "extrapolated_s_for_all_queries": n_h / q_rate,
+                                    "sample": f"MIHIndex::new on all {n_h} hashes + the first {q_pilot} queries of find_groups "
+                                              f"(max_dist {args.threshold}), {cores} threads"}}
+    del imgs, img_sample_dev
+    torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ the reference's own published cases (rank 0, N = 1)
-    if rank == 0 and world == 1:
-        rng = np.random.default_rng(1)
-        # (1) hamminghash.rs:336-412 / NOTES.txt:19: find_groups over 1M random u64 + an injected 5-cluster, max_dist 5
-        h64 = rng.integers(0, 2**64, 1_000_000, dtype=np.uint64)
-        target = 0xABCD_1234_5678_90EF
-        for v, i in zip([target, target ^ 1, target ^ 2, target ^ 0x8000, target ^ 0x8001], rng.choice(len(h64), 5, replace=False)):
-            h64[i] = v
-        eng.find_groups64(h64[:4096], 5)  # warm-up
-        t0 = time.perf_counter()
-        g64 = eng.find_groups64(h64, 5)
-        t_u64 = time.perf_counter() - t0
-        # (2) README.md:13: grouping 500 000 files (PDQ, 8 dihedral variants, default similarity 40)
-        nf = 500_000
-        coeffs = rng.normal(0, 20, (nf, 256)).astype(np.float32)
-        coeffs[1::1000] = coeffs[0::1000][: len(coeffs[1::1000])] + rng.normal(0, 0.5, (len(coeffs[1::1000]), 256)).astype(np.float32)
-        fh, _ = eng.pdq_hashes_from_coeffs(coeffs, want_hash=True, want_dihedral=False)
-        qual = np.full(nf, 100, np.int32)
-        t0 = time.perf_counter()
-        groups, cmp_count = eng.group_files_pdq(fh, 40, coeffs=coeffs, quality=qual)
-        t_group = time.perf_counter() - t0
-        # (3) pdqhash.rs:659-712 / NOTES.txt:41-46: bench_pdq_performance on the reference's tests/bench.jpg (1280x854):
-        #     100 x generate_pdq_features one image per call, and 30 000 x generate_dihedral_hashes
-        bench_jpg = None
-        jpg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "bench.jpg")
-        try:
-            from PIL import Image
-            photo = np.asarray(Image.open(jpg).convert("RGB"))
-        except Exception as e:  # Pillow or the fixture missing: the case is simply not reported
-            photo = None
-            bench_jpg = {"skipped": repr(e)}
-        if photo is not None:
-            eng.pdq_batcher_config(max_batch=1, max_wait_us=0)
-            one = eng.pdq_hash_one(photo)
-            t0 = time.perf_counter()
-            for _ in range(100):
-                eng.pdq_hash_one(photo)
-            t_one = (time.perf_counter() - t0) / 100
-            eng.pdq_batcher_config()
-            many = np.repeat(one[2][None, :], 30000, axis=0)
-            eng.pdq_hashes_from_coeffs(many[:64])
-            t0 = time.perf_counter()
-            eng.pdq_hashes_from_coeffs(many, want_hash=False, want_dihedral=True)
-            t_dih = time.perf_counter() - t0
-            bench_jpg = {"generate_pdq_features_ms_per_call": t_one * 1e3, "image": "1280x854 RGB8 from host memory, one image per call "
-                         "(H2D of 3.3 MB, GPU luma + box pre-downsample to 512x342, PDQ, D2H), decode excluded as in the reference",
-                         "reference_published_ms_per_call": 4.286,
-                         "generate_dihedral_hashes_30000_s": t_dih, "reference_published_30000_s": 0.2957,
-                         "reference_source": "NOTES.txt:41-46 (one thread, unstated CPU)"}
-        result["reference_cases"] = {
-            "bench_pdq_performance_bench_jpg": bench_jpg,
-            "find_groups_1M_u64_max_dist_5": {"seconds": t_u64, "groups": len(g64), "includes": "H2D copy, all-pairs sweep, host greedy clustering",
-                                              "reference_published_seconds": 12.27, "reference_source": "NOTES.txt:19 (14 threads, unstated CPU)"},
-            "group_500k_files_pdq_similarity_40": {"seconds": t_group, "groups": len(groups), "comparison_count": int(cmp_count),
-                                                   "includes": "8 dihedral variants per file from coefficients, variant sweep, union-find",
-                                                   "reference_published_seconds": "15-20", "reference_source": "README.md:13 (unstated CPU)"},
-        }
+    if rank == 0 and world == 1 and not args.no_reference_cases:
+        result["reference_cases"] = reference_cases(eng, np)
 
+    result["valid"] = valid
+    if problems:
+        result["problems"] = problems
     if rank == 0:
         print(json.dumps(result))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if not valid:
+        sys.exit(1)
+
+
+def reference_cases(eng, np):
+    rng = np.random.default_rng(1)
+    # (1) hamminghash.rs:336-412 / NOTES.txt:19: find_groups over 1M random u64 + an injected 5-cluster, max_dist 5
+    h64 = rng.integers(0, 2**64, 1_000_000, dtype=np.uint64)
+    target = 0xABCD_1234_5678_90EF
+    for v, i in zip([target, target ^ 1, target ^ 2, target ^ 0x8000, target ^ 0x8001], rng.choice(len(h64), 5, replace=False)):
+        h64[i] = v
+    eng.find_groups64(h64[:4096], 5)  # warm-up
+    t0 = time.perf_counter()
+    g64 = eng.find_groups64(h64, 5)
+    t_u64 = time.perf_counter() - t0
+    # (2) README.md:13: grouping 500 000 files (PDQ, 8 dihedral variants, default similarity 40)
+    nf = 500_000
+    coeffs = rng.normal(0, 20, (nf, 256)).astype(np.float32)
+    coeffs[1::1000] = coeffs[0::1000][: len(coeffs[1::1000])] + rng.normal(0, 0.5, (len(coeffs[1::1000]), 256)).astype(np.float32)
+    fh, _ = eng.pdq_hashes_from_coeffs(coeffs, want_hash=True, want_dihedral=False)
+    qual = np.full(nf, 100, np.int32)
+    t0 = time.perf_counter()
+    groups, cmp_count = eng.group_files_pdq(fh, 40, coeffs=coeffs, quality=qual)
+    t_group = time.perf_counter() - t0
+    # (3) pdqhash.rs:659-712 / NOTES.txt:41-46: bench_pdq_performance on the reference's tests/bench.jpg (1280x854):
+    #     100 x generate_pdq_features one image per call, and 30 000 x generate_dihedral_hashes
+    bench_jpg = None
+    jpg = os.path.join(ROOT, "tests", "golden", "bench.jpg")
+    try:
+        from PIL import Image
+        photo = np.asarray(Image.open(jpg).convert("RGB"))
+    except Exception as e:  # Pillow or the fixture missing: the case is simply not reported
+        photo = None
+        bench_jpg = {"skipped": repr(e)}
+    if photo is not None:
+        from rupphash_amd import pdqhash
+
+        eng.pdq_batcher_config(max_batch=1, max_wait_us=0)
+        one = eng.pdq_hash_one(photo)
+        t0 = time.perf_counter()
+        for _ in range(100):
+            eng.pdq_hash_one(photo)
+        t_one = (time.perf_counter() - t0) / 100
+        eng.pdq_batcher_config()
+        many = np.repeat(one[2][None, :], 30000, axis=0)
+        eng.pdq_hashes_from_coeffs(many[:64])
+        t0 = time.perf_counter()
+        eng.pdq_hashes_from_coeffs(many, want_hash=False, want_dihedral=True)
+        t_dih = time.perf_counter() - t0
+        # the per-file form the scanner calls (scanner.rs:1622): host scalar, no GPU round trip
+        feats = pdqhash.PdqFeatures(one[2])
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            feats.generate_dihedral_hashes()
+        t_dih_host = (time.perf_counter() - t0) / 2000
+        bench_jpg = {"generate_pdq_features_ms_per_call": t_one * 1e3, "image": "1280x854 RGB8 from host memory, one image per call "
+                     "(H2D of 3.3 MB, GPU luma + box pre-downsample to 512x342, PDQ, D2H), decode excluded as in the reference",
+                     "reference_published_ms_per_call": 4.286,
+                     "generate_dihedral_hashes_30000_s": t_dih, "reference_published_30000_s": 0.2957,
+                     "generate_dihedral_hashes_host_scalar_us_per_call": t_dih_host * 1e6, "reference_published_us_per_call": 9.86,
+                     "reference_source": "NOTES.txt:41-47 (one thread, unstated CPU)"}
+    return {
+        "bench_pdq_performance_bench_jpg": bench_jpg,
+        "find_groups_1M_u64_max_dist_5": {"seconds": t_u64, "groups": len(g64), "includes": "H2D copy, all-pairs sweep, host greedy clustering",
+                                          "reference_published_seconds": 12.27, "reference_source": "NOTES.txt:19 (14 threads, unstated CPU)"},
+        "group_500k_files_pdq_similarity_40": {"seconds": t_group, "groups": len(groups), "comparison_count": int(cmp_count),
+                                               "includes": "8 dihedral variants per file from coefficients, variant sweep, union-find",
+                                               "reference_published_seconds": "15-20", "reference_source": "README.md:13 (unstated CPU)"},
+    }
 
 
 if __name__ == "__main__":

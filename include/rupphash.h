@@ -117,6 +117,12 @@ int rph_pdq_hashes_from_coeffs(rph_ctx *ctx, const float *coeffs, uint32_t n, ui
 int rph_pdq_hashes_from_coeffs_dev(rph_ctx *ctx, const void *d_coeffs, uint32_t n, void *d_hash32,
                                    void *d_dihedral, void *stream);
 
+/* PdqFeatures::to_hash (pdqhash.rs:59-61) and generate_dihedral_hashes (:71-87) for ONE coefficient vector, on the host:
+ * compare + bit operations only, no GPU call, no context.  This is what the reference's per-file call sites bind
+ * (scanner.rs:1412 `f.to_hash()`, :1622 and :2223 `features.generate_dihedral_hashes()`); same bits as the batch kernels. */
+void rph_pdq_to_hash(const float *coeffs256, uint8_t *hash32_out);
+void rph_pdq_dihedral_one(const float *coeffs256, uint8_t *out8x32);
+
 /* Which PDQ kernel a context uses for 512x512 RGB8: 0 = generic multi-pass (any geometry), 1 = fused single-pass
  * with 64-px strips (default: 8 waves per CU, fastest), 2 = fused with 128-px strips (cache-line aligned loads,
  * 6 waves per CU).  All three produce identical bits.  Debug/bench. */
@@ -239,6 +245,31 @@ int rph_is_low_pdq_quality(int32_t quality);
 /* MIHIndex::new (hamminghash.rs:89-130) for [u8;32]: CSR arrays built on the
  * device.  offsets: 16*65536+1 u32, values: 16*n u32 (ascending id per bucket). */
 int rph_mih_build256(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t *offsets, uint32_t *values);
+/* MIHIndex::<u64>::new (hamminghash.rs:23-41, :89-130): 8 chunks of 8 bits.  offsets: 8*256+1 u32, values: 8*n u32. */
+int rph_mih_build64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, uint32_t *offsets, uint32_t *values);
+
+/* =====================================================================
+ * Cache record codecs (reference: src/db.rs), host scalar.  The layouts of the VALUES phdupes keeps per content hash,
+ * for bulk import/export between an existing cache and the engine's flat arrays.  The XChaCha20-Poly1305 envelope
+ * around them (db.rs:634-673) is the host application's business and is not touched here.
+ * ===================================================================== */
+#define RPH_PDQ_ALGO_VERSION 2u        /* db.rs:47 */
+#define RPH_HASH_RECORD_BYTES 33u      /* hash_db value: [PDQ_ALGO_VERSION || 32-byte hash], db.rs:1200-1211 */
+#define RPH_COEFF_RECORD_BYTES 1027u   /* coeff_db value of a 256-coefficient vector: [2 || 0x80 0x02 || 256 x f32 LE] */
+void rph_hash_record_encode(const uint8_t *hash32, uint8_t *out33);
+/* get_pdqhash's match (db.rs:683-696): 1 = Some(hash); 0 = None (another algorithm version or a length != 33: a miss, not an error) */
+int rph_hash_record_decode(const uint8_t *rec, size_t len, uint8_t *hash32_out);
+/* n records of 33 bytes each; decode returns the number of hits, present_out[i] (nullable) = 1/0, missing hashes zeroed */
+void rph_hash_records_encode(const uint8_t *hashes32, size_t n, uint8_t *out33n);
+size_t rph_hash_records_decode(const uint8_t *recs33n, size_t n, uint8_t *hashes32_out, uint8_t *present_out);
+/* coeff_db value: [PDQ_ALGO_VERSION || postcard(CachedCoefficients { coefficients: Vec<f32> })] = [2 || varint(len) || len x f32 LE]
+ * (db.rs:217-230, :1221-1231).  encode returns the record size (always; nothing is written if cap is smaller). */
+size_t rph_coeff_record_size(size_t n_coeffs);
+size_t rph_coeff_record_encode(const float *coeffs, size_t n_coeffs, uint8_t *out, size_t cap);
+/* get_coefficients' match (db.rs:742-755): 1 = Some (n_out coefficients written; the caller keeps them only if n_out == 256,
+ * scanner.rs:1265-1267); 0 = None (empty or another algorithm version); RPH_ERR_INVALID_ARG = the reference's
+ * lmdb::Error::Corrupted (malformed postcard payload); RPH_ERR_CAPACITY = more than `cap` coefficients (n_out still set). */
+int rph_coeff_record_decode(const uint8_t *rec, size_t len, float *coeffs_out, size_t cap, size_t *n_out);
 
 /* =====================================================================
  * 64-bit pHash bit operations (reference: src/phash.rs:137-255), host scalar

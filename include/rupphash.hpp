@@ -60,16 +60,17 @@ using Hash = std::array<uint8_t, 32>;
 struct PdqFeatures {                      // pdqhash.rs:48-51
     std::array<float, 256> coefficients;
 
+    // Host-scalar like the original (compare + bit operations on 256 floats: no GPU round trip per file, scanner.rs:1412, :1622)
     Hash to_hash() const                  // pdqhash.rs:59-61
     {
         Hash h{};
-        check(rph_pdq_hashes_from_coeffs(Context::get(), coefficients.data(), 1, h.data(), nullptr), "to_hash");
+        rph_pdq_to_hash(coefficients.data(), h.data());
         return h;
     }
     std::array<Hash, 8> generate_dihedral_hashes() const  // pdqhash.rs:71-87
     {
         std::array<Hash, 8> d{};
-        check(rph_pdq_hashes_from_coeffs(Context::get(), coefficients.data(), 1, nullptr, d[0].data()), "generate_dihedral_hashes");
+        rph_pdq_dihedral_one(coefficients.data(), d[0].data());
         return d;
     }
 };
@@ -88,12 +89,17 @@ inline std::optional<std::pair<PdqFeatures, float>> generate_pdq_features(const 
     if (!valid) return std::nullopt;
     return std::make_pair(f, q);
 }
-// pdqhash.rs:199-201
+// pdqhash.rs:199-201: the hash the kernel already computed beside the features is returned as is (no second pass)
 inline std::optional<std::pair<Hash, float>> generate_pdq(const ImageView &img)
 {
-    auto r = generate_pdq_features(img);
-    if (!r) return std::nullopt;
-    return std::make_pair(r->first.to_hash(), r->second);
+    Hash h{};
+    float q = 0.f;
+    uint8_t valid = 0;
+    check(rph_pdq_hash_one(Context::get(), img.data, img.width, img.height, img.channels, (size_t)img.width * img.channels, h.data(), &q,
+                           nullptr, &valid),
+          "generate_pdq");
+    if (!valid) return std::nullopt;
+    return std::make_pair(h, q);
 }
 // pdqhash.rs:224-235
 inline std::pair<uint32_t, uint32_t> calculate_target_dimensions(uint32_t w, uint32_t h, uint32_t max_dim)
@@ -159,6 +165,29 @@ private:
     std::vector<uint32_t> offsets_, values_;
 };
 
+// MIHIndex<u64> (hamminghash.rs:23-41, :82-149): 8 chunks of 8 bits, CSR built on the GPU.
+class MIHIndex64 {
+public:
+    explicit MIHIndex64(std::vector<uint64_t> hashes) : db_hashes_(std::move(hashes))
+    {
+        offsets_.resize(8 * 256 + 1);
+        values_.resize(8 * db_hashes_.size() + 1);
+        check(rph_mih_build64(Context::get(), db_hashes_.data(), db_hashes_.size(), offsets_.data(), values_.data()), "MIHIndex::new");
+    }
+    std::pair<const uint32_t *, size_t> bucket(size_t chunk, uint16_t value) const
+    {
+        const size_t flat = chunk * 256 + value;
+        return {values_.data() + offsets_[flat], offsets_[flat + 1] - offsets_[flat]};
+    }
+    const uint64_t &hash(DenseId id) const { return db_hashes_[id.index()]; }
+    size_t len() const { return db_hashes_.size(); }
+    const std::vector<uint64_t> &hashes() const { return db_hashes_; }
+
+private:
+    std::vector<uint64_t> db_hashes_;
+    std::vector<uint32_t> offsets_, values_;
+};
+
 // SparseBitSet (hamminghash.rs:152-189)
 class SparseBitSet {
 public:
@@ -193,6 +222,17 @@ inline std::vector<std::vector<uint32_t>> find_groups(const MIHIndex &index, uin
     uint32_t ng = 0;
     check(rph_find_groups256(Context::get(), n ? index.hashes()[0].data() : nullptr, n, max_dist, members.data(), offsets.data(), &ng),
           "find_groups");
+    std::vector<std::vector<uint32_t>> out(ng);
+    for (uint32_t g = 0; g < ng; g++) out[g].assign(members.begin() + offsets[g], members.begin() + offsets[g + 1]);
+    return out;
+}
+// find_groups::<u64> (hamminghash.rs:191-271 with the u64 impl :23-41)
+inline std::vector<std::vector<uint32_t>> find_groups(const MIHIndex64 &index, uint32_t max_dist)
+{
+    const size_t n = index.len();
+    std::vector<uint32_t> members(n ? n : 1), offsets(n / 2 + 2);
+    uint32_t ng = 0;
+    check(rph_find_groups64(Context::get(), index.hashes().data(), n, max_dist, members.data(), offsets.data(), &ng), "find_groups");
     std::vector<std::vector<uint32_t>> out(ng);
     for (uint32_t g = 0; g < ng; g++) out[g].assign(members.begin() + offsets[g], members.begin() + offsets[g + 1]);
     return out;

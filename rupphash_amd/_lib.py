@@ -54,6 +54,8 @@ SIGNATURES = {
     "rph_pdq_batcher_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rph_pdq_hashes_from_coeffs": (C.c_int, [_vp, _f32p, C.c_uint32, _u8p, _u8p]),
     "rph_pdq_hashes_from_coeffs_dev": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "rph_pdq_to_hash": (None, [_f32p, _u8p]),
+    "rph_pdq_dihedral_one": (None, [_f32p, _u8p]),
     "rph_pdq_set_kernel": (C.c_int, [_vp, C.c_int]),
     "rph_hamming_set_kernel": (C.c_int, [_vp, C.c_int]),
     "rph_hamming_prefix_dwords": (C.c_int, [C.c_uint32, C.c_int]),
@@ -80,6 +82,14 @@ SIGNATURES = {
     "rph_union_find_groups": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u32p, _u32p, C.POINTER(C.c_uint32)]),
     "rph_is_low_pdq_quality": (C.c_int, [C.c_int32]),
     "rph_mih_build256": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, _u32p]),
+    "rph_mih_build64": (C.c_int, [_vp, _u64p, C.c_uint64, _u32p, _u32p]),
+    "rph_hash_record_encode": (None, [_u8p, _u8p]),
+    "rph_hash_record_decode": (C.c_int, [_u8p, _sz, _u8p]),
+    "rph_hash_records_encode": (None, [_u8p, _sz, _u8p]),
+    "rph_hash_records_decode": (_sz, [_u8p, _sz, _u8p, _u8p]),
+    "rph_coeff_record_size": (_sz, [_sz]),
+    "rph_coeff_record_encode": (_sz, [_f32p, _sz, _u8p, _sz]),
+    "rph_coeff_record_decode": (C.c_int, [_u8p, _sz, _f32p, _sz, C.POINTER(C.c_size_t)]),
     "rph_phash_rotate_90": (C.c_uint64, [C.c_uint64]),
     "rph_phash_rotate_180": (C.c_uint64, [C.c_uint64]),
     "rph_phash_rotate_270": (C.c_uint64, [C.c_uint64]),
@@ -107,6 +117,31 @@ SIGNATURES = {
 _lib = None
 
 
+def _one_hip_runtime():
+    """Keep ONE HIP runtime in the process.  librupphash_hip.so needs `libamdhip64.so.7` (resolved from /opt/rocm); a PyTorch
+    wheel ships its own copy and asks for it as `libamdhip64.so`, which the loader does not match against an already loaded
+    /opt/rocm one -- the second runtime then finds the device taken ("No HIP GPUs are available").  If PyTorch is installed but
+    not imported yet, its copy is loaded first (by soname it then also satisfies this library), so a later `import torch`
+    shares it.  RPH_HIP_RUNTIME=system skips this (processes that never import torch)."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("RPH_HIP_RUNTIME") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime
+
+
 def load():
     """Load librupphash_hip.so (built by `make -C rupphash_amd/csrc` or __graft_entry__.build())."""
     global _lib
@@ -115,6 +150,7 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C rupphash_amd/csrc` (hipcc, --offload-arch=gfx950). "
                 "rupphash_amd has no CPU fallback.")
+        _one_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if the library does not export what the header declares

@@ -573,6 +573,29 @@ int rph_mih_build256(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t
     });
 }
 
+int rph_mih_build64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, uint32_t *offsets, uint32_t *values)
+{
+    return rph_guarded("rph_mih_build64", [&]() -> int {
+        if (!ctx || (!hashes64 && n) || !offsets || (!values && n)) {
+            rph_set_error("rph_mih_build64: null argument");
+            return RPH_ERR_INVALID_ARG;
+        }
+        RPH_HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n_off = (size_t)8 * 256 + 1;
+        DevBuf d_h, d_o, d_v;
+        RPH_TRY(d_h.alloc(n * 8));
+        RPH_TRY(d_o.alloc(n_off * 4));
+        RPH_TRY(d_v.alloc(n * 8 * 4));
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        RPH_HIP_CHECK(hipMemcpyAsync(d_h.p, hashes64, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        RPH_TRY(rph_launch_mih_build64(ctx, (const uint64_t *)d_h.p, n, (uint32_t *)d_o.p, (uint32_t *)d_v.p, ctx->stream));
+        RPH_HIP_CHECK(hipMemcpyAsync(offsets, d_o.p, n_off * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (n) RPH_HIP_CHECK(hipMemcpyAsync(values, d_v.p, n * 8 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return RPH_OK;
+    });
+}
+
 // ------------------------------------------------------------------------------------------
 // synthetic workloads, device memory helpers, events
 // ------------------------------------------------------------------------------------------

@@ -56,6 +56,8 @@ int rph_launch_hamming64_sweep(const uint64_t *d_hashes, uint64_t n, uint32_t th
                                rph_edge *d_edges, uint64_t cap, unsigned long long *d_count, hipStream_t stream, int use_mfma);
 int rph_launch_mih_build256(rph_ctx *ctx, const uint8_t *d_hashes, uint64_t n, uint32_t *d_offsets, uint32_t *d_values,
                             hipStream_t stream);
+int rph_launch_mih_build64(rph_ctx *ctx, const uint64_t *d_hashes, uint64_t n, uint32_t *d_offsets, uint32_t *d_values,
+                           hipStream_t stream);
 // synth_kernels.hip
 int rph_launch_synth_images(uint8_t *d_out, uint64_t first_k, uint32_t n, uint32_t w, uint32_t h, uint32_t seed,
                             hipStream_t stream);

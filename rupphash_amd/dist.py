@@ -81,50 +81,92 @@ def seg_blocks_of_part(n, part, nparts, s, tile=TILE):
     return [seg_block(b, nt, s) for b in range(part, seg_g(nt, s), nparts)]
 
 
-def all_gather_hashes(local_hashes, n_total, dist=None, device_tensor=False):
-    """One all-gather of the per-rank hash shards into the full (n_total, 32) array on every rank.
+def _backend_is_device_only(dist):
+    """True when the process group can only move device tensors (backend "nccl" = RCCL alone, no CPU backend beside it)"""
+    b = str(dist.get_backend()).lower()
+    return "nccl" in b and "gloo" not in b
 
-    Shards must follow shard_range().  With `dist is None` (single process) the input is returned.
+
+def _collective_tensor(t, dist, device):
+    """the tensor in the memory space this process group's collectives accept: device memory under nccl (RCCL), host under gloo"""
+    import torch
+
+    if _backend_is_device_only(dist):
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        return t.to(device)
+    return t.cpu()
+
+
+def all_gather_rows(local_rows, n_total, dist=None, device=None):
+    """One all-gather of per-rank row shards (rows of any byte width: 32-byte hashes, 256-byte dihedral blocks, 1-byte flags)
+    into the full (n_total, width) array on every rank.
+
+    Shards must follow shard_range().  numpy in -> numpy out; torch tensor in -> tensor out on the input's device.  The
+    collective itself runs where the backend needs it (device memory under nccl = RCCL, host memory under gloo).
     Unequal shards (n_total % world != 0) are padded to the largest shard for the collective."""
     import torch
 
     if dist is None or dist.get_world_size() == 1:
-        return local_hashes
+        return local_rows
     world, rank = dist.get_world_size(), dist.get_rank()
-    t = local_hashes if isinstance(local_hashes, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local_hashes, np.uint8))
-    t = t.reshape(-1, 32)
+    is_tensor = isinstance(local_rows, torch.Tensor)
+    t = local_rows if is_tensor else torch.from_numpy(np.ascontiguousarray(local_rows, np.uint8))
+    home = t.device
+    t = t.reshape(t.shape[0], -1)
+    width = t.shape[1]
     sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
     assert t.shape[0] == sizes[rank], (t.shape, sizes, rank)
+    t = _collective_tensor(t, dist, device)
     big = max(sizes)
     if big != t.shape[0]:
-        pad = torch.zeros((big - t.shape[0], 32), dtype=torch.uint8, device=t.device)
+        pad = torch.zeros((big - t.shape[0], width), dtype=t.dtype, device=t.device)
         t = torch.cat([t, pad])
-    out = torch.empty((world * big, 32), dtype=torch.uint8, device=t.device)
+    out = torch.empty((world * big, width), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous())
     if any(s != big for s in sizes):
         out = torch.cat([out[r * big:r * big + sizes[r]] for r in range(world)])
-    return out if isinstance(local_hashes, torch.Tensor) else out.cpu().numpy()
+    if is_tensor:
+        return out.to(home)
+    return out.cpu().numpy()
 
 
-def gather_edges(local_edges, dist=None, dst=0):
-    """variable-length edge lists -> rank `dst` (None elsewhere)"""
+def all_gather_hashes(local_hashes, n_total, dist=None, device=None):
+    """The exchange step of the path: (n_local, 32) hash shards -> (n_total, 32) on every rank (see all_gather_rows)."""
+    import torch
+
+    if dist is None or dist.get_world_size() == 1:
+        return local_hashes
+    if isinstance(local_hashes, torch.Tensor):
+        return all_gather_rows(local_hashes.reshape(-1, 32), n_total, dist, device)
+    return all_gather_rows(np.ascontiguousarray(local_hashes, np.uint8).reshape(-1, 32), n_total, dist, device)
+
+
+def gather_edges(local_edges, dist=None, dst=0, device=None):
+    """variable-length edge lists -> rank `dst` (None elsewhere).
+
+    Works on every backend: the counts travel in one all-gather of an int64, the edges in one all-gather of buffers padded
+    to the largest count (nccl has no CPU path, and `gather` of unequal sizes is not portable; the lists are tiny)."""
     import torch
 
     local_edges = np.ascontiguousarray(local_edges, EDGE_DTYPE)
     if dist is None or dist.get_world_size() == 1:
         return local_edges
     world, rank = dist.get_world_size(), dist.get_rank()
-    counts = [None] * world
-    dist.all_gather_object(counts, int(len(local_edges)))
-    big = max(counts) if counts else 0
-    buf = np.zeros(max(big, 1), EDGE_DTYPE)
+    cnt = _collective_tensor(torch.tensor([len(local_edges)], dtype=torch.int64), dist, device)
+    counts_t = torch.empty(world, dtype=torch.int64, device=cnt.device)
+    dist.all_gather_into_tensor(counts_t, cnt)
+    counts = [int(c) for c in counts_t.cpu().tolist()]
+    big = max(max(counts), 1)
+    buf = np.zeros(big, EDGE_DTYPE)
     buf[: len(local_edges)] = local_edges
-    t = torch.from_numpy(buf.view(np.uint8).reshape(-1, EDGE_DTYPE.itemsize).copy())
-    gathered = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-    dist.gather(t, gathered, dst=dst)
+    t = _collective_tensor(torch.from_numpy(buf.view(np.uint8).reshape(big, EDGE_DTYPE.itemsize).copy()), dist, device)
+    out = torch.empty((world * big, EDGE_DTYPE.itemsize), dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous())
     if rank != dst:
         return None
-    parts = [g.numpy().reshape(-1).view(EDGE_DTYPE)[: counts[r]] for r, g in enumerate(gathered)]
+    host = out.cpu().numpy().reshape(world, big, EDGE_DTYPE.itemsize)
+    parts = [np.ascontiguousarray(host[r, : counts[r]]).reshape(-1).view(EDGE_DTYPE) for r in range(world)]
     return np.concatenate(parts) if parts else np.zeros(0, EDGE_DTYPE)
 
 
@@ -152,3 +194,98 @@ def hash_and_group(first_image, n_images_total, make_images_fn, hash_fn, thresho
     lo, hi = shard_range(n_images_total, rank, world)
     hashes = hash_fn(make_images_fn(first_image + lo, hi - lo))      # no communication
     return grouped_all_pairs(hashes, n_images_total, threshold, sweep_fn, group_fn, dist)
+
+
+def engine_fns(eng, semantics="union_find"):
+    """(hash_fn, sweep_fn, group_fn) of a real Engine for hash_and_group / grouped_all_pairs: the kernels behind the C ABI"""
+
+    def hash_fn(imgs):
+        return eng.pdq_hash_batch(imgs, want_quality=False)["hash"]
+
+    def sweep_fn(all_hashes, thr, part, nparts):
+        return eng.hamming_all_pairs(all_hashes, thr, part=part, nparts=nparts)
+
+    group_fn = eng.union_find_groups if semantics == "union_find" else eng.find_groups_from_edges
+    return hash_fn, sweep_fn, group_fn
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Device-resident form of the whole path (BASELINE config 4), production grouping semantics
+# ---------------------------------------------------------------------------------------------------------------------
+def stored_quality_lowconf(quality):
+    """quality in [0,1] (device tensor) -> uint8 low-confidence flags: round(q * 100) clamped to 0..100 (scanner.rs:1416-1417,
+    round half away from zero) < PDQ_MIN_QUALITY (scanner.rs:1588-1594)"""
+    import torch
+
+    stored = torch.clamp(torch.floor(quality * 100.0 + 0.5), 0.0, 100.0)
+    return (stored < 50.0).to(torch.uint8)
+
+
+def hash_and_group_device(eng, images, n_total, similarity, dist=None, variants=True, w=512, h=512, channels=3, edge_cap=1 << 20,
+                          timings=None):
+    """Images resident in HBM -> PDQ hash -> all-gather -> sweep -> groups, the reference's scan-then-group call
+    (scanner.rs:1146-1551: hash every file, then group_files_generic) with the data never leaving the devices until the
+    (tiny) edge lists go to rank 0.
+
+    images: torch uint8 tensor on this rank's GPU holding ITS shard (shard_range(n_total, rank, world)) of the image sequence,
+            (n_local, h * w * channels) or (n_local, h, w, channels), packed.
+    variants=True: production semantics of group_files_generic + PdqStrategy (8 dihedral variants per file as rows, the
+            low-quality rule, union-find; scanner.rs:1596-1823).  The exchange is then ONE all-gather of the per-file
+            dihedral blocks (8 x 32 B; slot 0 is the hash itself) plus one of the 1-byte low-confidence flags.
+    variants=False: plain all-pairs over the hashes (BASELINE config 5's sweep), exchange = the 32-byte hashes.
+    Kernels, collectives and copies are enqueued on torch's current stream.
+    Returns (groups or None, info): groups on rank 0 (connected components, members ascending, by first member)."""
+    import time
+
+    import torch
+
+    world = 1 if dist is None else dist.get_world_size()
+    rank = 0 if dist is None else dist.get_rank()
+    dev = images.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    lo, hi = shard_range(n_total, rank, world)
+    n_local = hi - lo
+    assert images.shape[0] == n_local, (images.shape, lo, hi)
+    t0 = time.perf_counter()
+    d_hash = torch.empty((n_local, 32), dtype=torch.uint8, device=dev)
+    d_q = torch.empty(n_local, dtype=torch.float32, device=dev)
+    d_dih = torch.empty((n_local, 8, 32), dtype=torch.uint8, device=dev) if variants else None
+    eng.pdq_hash_batch_dev(images.data_ptr(), n_local, w, h, channels, d_hash.data_ptr(), d_quality=d_q.data_ptr(),
+                           d_dihedral=d_dih.data_ptr() if variants else None, stream=stream)
+    low = stored_quality_lowconf(d_q)
+    # ---- the one exchange step (RCCL all-gather under nccl)
+    if variants:
+        all_dih = all_gather_rows(d_dih.reshape(n_local, 256), n_total, dist, dev).reshape(n_total, 8, 32)
+        all_low = all_gather_rows(low.reshape(n_local, 1), n_total, dist, dev).reshape(n_total).contiguous()
+        all_hash = all_dih[:, 0, :].contiguous()
+    else:
+        all_hash = all_gather_rows(d_hash, n_total, dist, dev)
+        all_dih, all_low = None, None
+    if timings is not None:
+        torch.cuda.synchronize(dev)
+        timings["hash_and_exchange_s"] = time.perf_counter() - t0
+    # ---- this rank's share of the block pairs; no communication
+    cap = int(edge_cap)
+    while True:
+        d_edges = torch.empty((cap, EDGE_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        if variants:
+            eng.hamming_variant_pairs_dev(all_dih.data_ptr(), 8, all_hash.data_ptr(), n_total, similarity, d_edges.data_ptr(), cap,
+                                          d_count.data_ptr(), d_low_conf=all_low.data_ptr(), part=rank, nparts=world, stream=stream)
+        else:
+            eng.hamming_all_pairs_dev(all_hash.data_ptr(), n_total, similarity, d_edges.data_ptr(), cap, d_count.data_ptr(),
+                                      part=rank, nparts=world, stream=stream)
+        found = int(d_count.item())
+        if found <= cap:
+            break
+        cap = found + found // 8 + 1024  # rare: more edges than expected, sweep again into a buffer that fits
+    local_edges = d_edges[:found].cpu().numpy().reshape(-1).view(EDGE_DTYPE) if found else np.zeros(0, EDGE_DTYPE)
+    merged = gather_edges(local_edges, dist, dst=0, device=dev)  # tiny
+    info = {"n_local": n_local, "edges_local": found, "ranks_in_collective": world}
+    if rank != 0:
+        return None, info
+    info["edges_total"] = int(len(merged))
+    groups = eng.union_find_groups(merged, n_total)  # serial in the reference too (scanner.rs:1781-1817)
+    if timings is not None:
+        timings["total_s"] = time.perf_counter() - t0
+    return groups, info

@@ -250,6 +250,14 @@ class Engine:
         check(self.L.rph_mih_build256(self.ctx, _ptr(hashes), n, _ptr(offsets), _ptr(values)), "rph_mih_build256")
         return offsets, values[: 16 * n]
 
+    def mih_build64(self, hashes):
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        n = len(hashes)
+        offsets = np.zeros(8 * 256 + 1, np.uint32)
+        values = np.zeros(max(8 * n, 1), np.uint32)
+        check(self.L.rph_mih_build64(self.ctx, _ptr(hashes), n, _ptr(offsets), _ptr(values)), "rph_mih_build64")
+        return offsets, values[: 8 * n]
+
     # ---- synthetic workloads ----
     def synth_images_dev(self, d_out, first_k, n, w=512, h=512, seed=0x5EED2026, stream=None):
         check(self.L.rph_synth_images_dev(self.ctx, d_out, first_k, n, w, h, seed, stream), "rph_synth_images_dev")

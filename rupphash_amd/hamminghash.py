@@ -105,11 +105,20 @@ class SparseBitSet:
 
 
 class MIHIndex64:
-    """MIHIndex<u64>: only what find_groups::<u64> needs (the hashes); the sweep replaces the probe tables."""
+    """MIHIndex<u64>: CSR multi-index (8 chunks of 8 bits) built on the GPU (rph_mih_build64), lazily: find_groups::<u64>
+    itself only needs the hashes (the sweep replaces the probe tables)."""
 
     def __init__(self, hashes, engine=None):
         self.engine = engine or default_engine()
         self.db_hashes = np.ascontiguousarray(hashes, np.uint64)
+        self._csr = None
+
+    def bucket(self, chunk, value):
+        if self._csr is None:
+            self._csr = self.engine.mih_build64(self.db_hashes)
+        offsets, values = self._csr
+        flat = chunk * HammingHash64.NUM_BUCKETS + int(value)
+        return values[offsets[flat]:offsets[flat + 1]]
 
     def hash(self, dense_id):
         return int(self.db_hashes[int(dense_id)])

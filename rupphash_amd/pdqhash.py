@@ -7,10 +7,13 @@
     generate_pdq(image) -> Option<([u8; 32], f32)>               :199-201
 plus the batch forms the GPU wants.  `image` is a numpy uint8 array: (h, w) = Luma8 (borrowed as
 is, :173), (h, w, 3) = Rgb8, (h, w, 4) = Rgba8 (alpha ignored, :279).  None is returned for
-w or h < 5 exactly like the reference.  All arithmetic runs on the GPU.
+w or h < 5 exactly like the reference.  Image hashing runs on the GPU; to_hash / generate_dihedral_hashes of ONE
+feature vector are the library's host-scalar functions (compare + bit operations, what the reference's per-file
+call sites scanner.rs:1412, :1622 bind); the batch forms go to the GPU.
 """
 import numpy as np
 
+from . import _lib
 from .engine import default_engine
 
 MIN_HASHABLE_DIM = 5      # pdqhash.rs:17
@@ -25,13 +28,15 @@ class PdqFeatures:
         c = np.ascontiguousarray(coefficients, np.float32).reshape(256)
         self.coefficients = c
 
-    def to_hash(self, engine=None):
-        h, _ = (engine or default_engine()).pdq_hashes_from_coeffs(self.coefficients, want_hash=True, want_dihedral=False)
-        return h[0]
+    def to_hash(self):
+        out = np.zeros(32, np.uint8)
+        _lib.load().rph_pdq_to_hash(self.coefficients.ctypes.data, out.ctypes.data)
+        return out
 
-    def generate_dihedral_hashes(self, engine=None):
-        _, d = (engine or default_engine()).pdq_hashes_from_coeffs(self.coefficients, want_hash=False, want_dihedral=True)
-        return d[0]
+    def generate_dihedral_hashes(self):
+        out = np.zeros((8, 32), np.uint8)
+        _lib.load().rph_pdq_dihedral_one(self.coefficients.ctypes.data, out.ctypes.data)
+        return out
 
 
 def generate_pdq_features(image, engine=None):

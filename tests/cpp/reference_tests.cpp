@@ -172,6 +172,15 @@ static void generate_pdq_features_from_many_threads()  // scanner.rs:1202-1205, 
 static void test_high_similarity_support()  // hamminghash.rs:283-332
 {
     EXPECT(hamminghash::HammingHash<uint64_t>::hamming_distance(0, 0xFFF) == 12, "u64 distance");
+    {  // pHash (u64) at max_dist 12: NOTES.txt:13-14
+        hamminghash::MIHIndex64 index64({0ull, 0xFFFull});
+        const auto g64 = hamminghash::find_groups(index64, 12);
+        EXPECT(!g64.empty() && g64[0] == (std::vector<uint32_t>{0, 1}), "pHash Group should contain both indices");
+        // CSR of MIHIndex<u64>: chunk 0 of 0xFFF is 0xFF, chunk 1 is 0x0F, chunks 2..7 are 0 for both
+        EXPECT(index64.bucket(0, 0xFF).second == 1 && index64.bucket(0, 0xFF).first[0] == 1, "bucket(0, 0xFF) = [1]");
+        EXPECT(index64.bucket(1, 0x0F).second == 1 && index64.bucket(1, 0).second == 1, "chunk 1 buckets");
+        EXPECT(index64.bucket(5, 0).second == 2 && index64.bucket(5, 0).first[0] == 0 && index64.bucket(5, 0).first[1] == 1, "bucket(5, 0) = [0, 1]");
+    }
     hamminghash::Hash256 base{}, target{};
     for (int i = 0; i < 30; i++) target[i / 8] |= (uint8_t)(1u << (i % 8));
     hamminghash::MIHIndex index({base, target});

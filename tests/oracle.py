@@ -19,6 +19,13 @@ REF_OK, REF_TOO_SMALL, REF_NEEDS_RESIZE = 0, 1, 2
 
 
 def build(force=False):
+    """(Re)build the oracle when missing or stale.  With RPH_ORACLE_NO_BUILD=1 (bench.py sets it) nothing is ever spawned:
+    the library __graft_entry__.build() produced is used as it is, and a missing one is an error -- a `make` child of a process
+    that holds the GPU, or that runs under a profiler's preload, would be an exec from a GPU-initialised process."""
+    if os.environ.get("RPH_ORACLE_NO_BUILD") == "1" and not force:
+        if not os.path.exists(_SO):
+            raise ImportError(f"{_SO} is missing: run `python __graft_entry__.py` (build()) first; bench.py never builds the oracle itself")
+        return _SO
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h")) or f == "Makefile"]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])

@@ -332,6 +332,25 @@ def test_mih_build_matches_reference_csr(eng, oracle):
     assert np.array_equal(off, woff) and np.array_equal(vals, wvals)
 
 
+def test_mih_build64_matches_reference_csr(eng, oracle):
+    """MIHIndex::<u64>::new (hamminghash.rs:23-41, :89-130): 8 chunks of 8 bits, ids ascending inside a bucket"""
+    rng = np.random.default_rng(7)
+    hashes = rng.integers(0, 2**64, 50_000, dtype=np.uint64)
+    hashes[1000:1200] = hashes[0]                       # a crowded bucket in every chunk
+    hashes[2000:3000] &= np.uint64(0xFFFFFFFFFFFF00FF)  # chunk 1 == 0 for a thousand hashes
+    off, vals = eng.mih_build64(hashes)
+    woff, wvals = oracle.MIHIndex(oracle.KIND_U64, hashes).csr()
+    assert np.array_equal(off, woff) and np.array_equal(vals, wvals)
+    from rupphash_amd import hamminghash
+
+    idx = hamminghash.MIHIndex64(hashes, engine=eng)
+    ref = oracle.MIHIndex(oracle.KIND_U64, hashes)
+    for chunk, value in [(0, int(hashes[0]) & 0xFF), (1, 0), (7, int(hashes[5]) >> 56), (3, 255)]:
+        assert np.array_equal(idx.bucket(chunk, value), ref.bucket(chunk, value))
+    off0, vals0 = eng.mih_build64(np.zeros(0, np.uint64))
+    assert not off0.any() and len(vals0) == 0
+
+
 # ------------------------------------------------------------------ full-size, construction-known answers
 @pytest.mark.parametrize("kernel,n", [(2, 1_000_000), (1, 1_000_000), (0, 1_000_000), (2, 3_100_000), (1, 3_100_000)])
 def test_one_million_hashes_threshold_32(eng, oracle, kernel, n):

@@ -65,7 +65,7 @@ void run(const char *name, int waves_per_simd)
 }
 int main()
 {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 2, 3, 4, 6, 8}) {
         run<0, 1>("v_add_f32 dependent", w);
         run<0, 8>("v_add_f32 independent", w);
         run<1, 1>("v_fma_mix_f32 dependent", w);
