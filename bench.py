@@ -72,7 +72,8 @@ def parse_args():
     ap.add_argument("--threshold", type=int, default=32)
     ap.add_argument("--hamming-steps", type=int, default=0, help="default: same as --steps")
     ap.add_argument("--pdq-kernel", type=int, default=1, help="1 = fused, 64-px strips (default), 2 = fused, 128-px strips, 0 = generic multi-pass")
-    ap.add_argument("--hamming-kernel", type=int, default=2, help="2 = fp4 MFMA fast path (default), 1 = int8 MFMA fast path, 0 = VALU xor + popcount")
+    ap.add_argument("--hamming-kernel", type=int, default=2, help="2 = fp4 MFMA fast path (default: popcount-sorted {0,1} operands), 3 = fp4 MFMA with +-1 operands, "
+                    "1 = int8 MFMA fast path, 0 = VALU xor + popcount")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal: ranks may "
                     "share one GPU, collectives are staged through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -345,12 +346,15 @@ def main():
                "achieved_hbm_frac_of_peak": pairs_per_s_rank * HAMMING_HBM_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS,
                "hbm_note": "algorithmic tile bytes (64/T B per pair, T = 1024) / sweep time: far below peak by design -- the tiles are "
                            "reused from LDS/registers; the binding roof is the matrix pipe"}
-        if args.hamming_kernel == 2:
+        if args.hamming_kernel >= 2:
             # fp4 MFMA fast path: one v_mfma_scale_f32_32x32x64_f8f6f4 (131 072 fp4 ops) per 64-bit slice of 1024 pairs -> 64 * PW ops per pair,
             # against the dense fp4 peak (2 x the fp8 / int8 peak)
             h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": 2 * MFMA_I8_OPS_PER_S / 1e12, "unit": "TOP/s (fp4)",
                       "frac": pairs_per_s_rank * 64 * pw / (2 * MFMA_I8_OPS_PER_S), "int8_equivalent_ops_per_pair": 64 * pw, "prefix_dwords": pw,
-                      "kernel_ms": h_kernel_ms, "kernel": "hamming_mfma_kernel<FmtFp4>"}
+                      "kernel_ms": h_kernel_ms,
+                      "kernel": "hamming_mfma_kernel<FmtFp4ZO> (popcount-sorted {0,1} operands)" if args.hamming_kernel == 2 and n_h >= 32768 else "hamming_mfma_kernel<FmtFp4> (+-1 operands)",
+                      "note": "power-limited, not pipe-limited: the in-kernel clock under this MFMA load is 1.8-2.0 GHz (tools/sweep_loop.hip), "
+                              "the peak above is priced at 2.4 GHz"}
         elif args.hamming_kernel == 1:
             # int8 MFMA fast path: one v_mfma_i32_32x32x32_i8 (65 536 int8 ops) per 32-bit slice of 1024 pairs -> 64 * PW ops per pair
             h_roof = {"bound": "mfma", "achieved": pairs_per_s_rank * 64 * pw / 1e12, "peak": MFMA_I8_OPS_PER_S / 1e12,

@@ -143,8 +143,10 @@ uint32_t rph_hamming_distance64(uint64_t a, uint64_t b);
 uint16_t rph_get_chunk256(const uint8_t *h32, uint32_t chunk_idx);
 uint16_t rph_get_chunk64(uint64_t h, uint32_t chunk_idx);
 
-/* Which formulation the sweep's fast path uses: 2 = fp4 MFMA (+-1 encoded bits as e2m1, default), 1 = int8 MFMA,
- * 0 = VALU xor + popcount.  All feed the same exact completion and report identical edges.  Debug/bench. */
+/* Which formulation the sweep's fast path uses: 2 = fp4 MFMA (default: bits as e2m1 +-1; plain all-pairs sweeps of >= 32768
+ * hashes run on a popcount-sorted copy with bits as {0, 1}, which the power-limited chip clocks ~10 % higher), 3 = fp4 MFMA with
+ * +-1 operands everywhere, 4 = the sorted {0, 1} form at every size (tests), 1 = int8 MFMA, 0 = VALU xor + popcount.  All feed the same exact completion and report the same edge
+ * set.  Debug/bench. */
 int rph_hamming_set_kernel(rph_ctx *ctx, int which);
 /* Width (in 32-bit words, 4..8) of the hash prefix the sweep's fast path examines for `threshold` under formulation `kernel`
  * (as in rph_hamming_set_kernel).  Informational (bench.py prices the fast path with it): results never depend on it. */

@@ -31,6 +31,8 @@
 // (against 64 lanes / 6 clk for v_xor + v_bcnt, a half-rate VALU op on gfx950 -- tools/valu_rate.hip).  Row fragments stay in
 // VGPRs, column chunks are expanded once through a 256-entry LUT into LDS.  Candidates (partial distance <= threshold) go through
 // the same exact completion as the VALU kernel.  64-bit hashes use the fp4 format with the whole hash as one slice.
+#include <hipcub/hipcub.hpp>
+
 #include "rph_internal.h"
 
 namespace {
@@ -58,6 +60,10 @@ struct SweepArgs {
     rph_edge *edges;
     unsigned long long cap;
     unsigned long long *count;
+    // popcount-sorted {0,1} formulation (FmtFp4ZO): rows == cols is the hash array sorted by the popcount of its prefix,
+    // pcs[k] that popcount (ascending), perm[k] the index of sorted hash k in the caller's array
+    const uint32_t *perm;
+    const uint16_t *pcs;
 };
 
 __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) { return (uint32_t)__builtin_popcount(x) + acc; }
@@ -136,6 +142,11 @@ __device__ __forceinline__ void complete_pair(const SweepArgs &a, const uint32_t
         rph_edge e;
         e.i = (uint32_t)owner;
         e.j = (uint32_t)col;
+        if (a.perm) {  // sorted sweep: back to the caller's indices, i < j (distance and probe key are symmetric)
+            const uint32_t pi = a.perm[owner], pj = a.perm[col];
+            e.i = pi < pj ? pi : pj;
+            e.j = pi < pj ? pj : pi;
+        }
         e.d = (uint16_t)d;
         e.flags = (uint16_t)flags;
         a.edges[at] = e;
@@ -277,9 +288,9 @@ struct FmtI8 {  // +-1 as int8: v_mfma_i32_32x32x32_i8 evaluates a 32-bit slice 
     }
     static __device__ __forceinline__ Acc zero() { return Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
     static __device__ __forceinline__ Acc mfma(v4i a, v4i b, Acc c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ Scalar max3(Scalar a, Scalar b, Scalar c) { return max3i(a, b, c); }
-    static __device__ __forceinline__ Scalar max2(Scalar a, Scalar b) { return max2i(a, b); }
-    static __device__ __forceinline__ Scalar thresh(int t) { return t; }
+    // the screen compares integer keys: the accumulator itself
+    static __device__ __forceinline__ int key(Scalar x) { return x; }
+    static __device__ __forceinline__ int thresh_key(int t) { return t; }
 };
 
 struct FmtFp4 {  // +-1 as e2m1 (0x2 / 0xA): v_mfma_scale_f32_32x32x64_f8f6f4 at unit scales evaluates a 64-bit slice; f32 accumulation exact
@@ -319,9 +330,37 @@ struct FmtFp4 {  // +-1 as e2m1 (0x2 / 0xA): v_mfma_scale_f32_32x32x64_f8f6f4 at
         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0}, v8i{b[0], b[1], b[2], b[3], 0, 0, 0, 0}, c, 4,
                                                                4, 0, 127, 0, 127);
     }
-    static __device__ __forceinline__ Scalar max3(Scalar a, Scalar b, Scalar c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-    static __device__ __forceinline__ Scalar max2(Scalar a, Scalar b) { return __builtin_fmaxf(a, b); }
-    static __device__ __forceinline__ Scalar thresh(int t) { return (float)t; }
+    // The screen compares integer keys: the f32 bit pattern.  For a positive threshold `x >= t` is the same as
+    // `bits(x) >= bits(t)` as signed integers (non-negative floats order like their bit patterns, negative ones are negative
+    // integers), and an integer max needs no NaN canonicalisation (a float max compiles to two extra v_max_f32 x, x per tile).
+    // t <= 0 (threshold >= 16 PW: every unrelated pair is a candidate anyway) -> INT_MIN: everything goes to the exact completion.
+    static __device__ __forceinline__ int key(Scalar x) { return __builtin_bit_cast(int, x); }
+    static __device__ __forceinline__ int thresh_key(int t) { return t > 0 ? __builtin_bit_cast(int, (float)t) : (int)0x80000000; }
+};
+
+// The same instruction on bits encoded as {0, 1} (e2m1 codes 0x0 / 0x2): dot = popcount(a & b), so
+//     d = popcount(a) + popcount(b) - 2 dot      and      d <= threshold  <=>  dot >= (pa + pb - threshold) / 2.
+// Three quarters of the products are zero, and the chip -- which runs this kernel against its power limit, not against the matrix
+// pipe's cycle count (tools/sweep_loop.hip: in-kernel clock 1.78 GHz on +-1 operands, 1.92-1.98 GHz on {0,1} operands, same cycles)
+// -- clocks ~10 % higher.  The price is that the threshold now depends on the pair; with the hashes SORTED by the popcount of their
+// prefix (one stable radix sort per call, rph_launch_hamming_sweep) pa is constant over a row block and pb over a column chunk up
+// to the few blocks that straddle a step, where the smaller value is used (never misses a pair; the completion is exact).
+struct FmtFp4ZO : FmtFp4 {
+    static constexpr bool ZERO_ONE = true;
+    static __device__ __forceinline__ Lut lut_entry(uint32_t byte)
+    {
+        uint32_t e = 0;
+        for (int i = 0; i < 8; i++) e |= (((byte >> i) & 1u) ? 0x2u : 0x0u) << (4 * i);
+        return e;
+    }
+};
+template <class F>
+struct is_zero_one {
+    static constexpr bool value = false;
+};
+template <>
+struct is_zero_one<FmtFp4ZO> {
+    static constexpr bool value = true;
 };
 
 // Exact completion of one u64 pair (impl HammingHash for u64, hamminghash.rs:23-41): distance, i < j, find_groups reachability
@@ -362,9 +401,9 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
     constexpr int MF_RB = F::row_blocks(PW);      // 32-row blocks per wave and pass
     constexpr int PASS_ROWS = 4 * 32 * MF_RB;     // rows one pass of the 4 waves covers; T_FILES / PASS_ROWS passes per tile
     static_assert(!U64 || PW == 2, "u64 hashes are swept at full width");
-    static_assert((CHUNK / 32) * (MF_RB / 2) <= 32, "candidate bitmap of a chunk is one dword");
+    constexpr int NCB = CHUNK / 32;               // 32-column blocks per chunk
+    constexpr int NRP = MF_RB / 2;                // row-block pairs per wave and pass (one screen result each per chunk)
     typedef typename F::Acc Acc;
-    typedef typename F::Scalar Scalar;
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * CHUNK * PITCH];
     __shared__ typename F::Lut s_lut[256];
     __shared__ uint2 s_q[4][QCAP];      // one queue per wave: filled and drained by the same wave, no barrier needed
@@ -387,7 +426,8 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c32 = lane & 31, h = lane >> 5;
-    const Scalar thresh_dot = F::thresh(32 * PW - 2 * (int)a.threshold);  // partial distance <= threshold  <=>  dot >= 32 PW - 2 threshold
+    constexpr bool ZO = is_zero_one<F>::value;
+    const int thresh_key = F::thresh_key(32 * PW - 2 * (int)a.threshold);  // +-1 encoding: partial distance <= threshold  <=>  dot >= 32 PW - 2 threshold
     const uint32_t nv = a.n_variants;
 
     for (uint32_t vp = 0; vp < nv * (T_FILES / PASS_ROWS); vp++) {
@@ -421,6 +461,14 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
             for (int f = 0; f < NF; f++) A[rb][f] = F::a_frag(s_lut, d, f, h);
         }
 
+        // {0,1} encoding: smallest prefix popcount of each row-block pair (ascending order: its first row; rows past the end are copies of hash 0)
+        int pa_min[NRP];
+#pragma unroll
+        for (int p = 0; p < NRP; p++) {
+            const unsigned long long r_first = row0 + wrow + 64ull * p;
+            pa_min[p] = ZO ? (int)a.pcs[(r_first + 63 < a.n) ? r_first : 0ull] : 0;
+        }
+
         // column chunks are double buffered: the packed dwords of chunk i + 1 are fetched into registers while chunk i
         // is swept and expanded into the other LDS buffer afterwards, so global latency never sits between two chunks
         constexpr int PER_THREAD = (CHUNK * PW + MF_BLOCK - 1) / MF_BLOCK;
@@ -447,36 +495,42 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
         uint32_t undrained = 0;
         for (uint32_t cbase = 0; cbase < ncols; cbase += CHUNK, which ^= 1) {
             uint8_t *s_b = s_buf + which * (CHUNK * PITCH);
+            const int pb_min = ZO ? (int)a.pcs[col0 + cbase] : 0;  // smallest prefix popcount of the chunk's columns; issued here, used after the MFMA loop
             expand(cbase, s_b);
             __syncthreads();  // chunk visible (and the queue reset of the previous chunk)
             if (cbase + CHUNK < ncols) fetch(cbase + CHUNK);
 
             // ---- fast path: MFMA + VALU screen only.  No global memory operation lives in this loop (candidates go to
             // an LDS queue), so the compiler never has to drain vmcnt here and the prefetch above stays in flight.
-            uint32_t cand = 0;  // bit (cb * MF_RB / 2 + rb / 2): this lane saw a candidate among its 32 pairs of column block cb, row blocks rb, rb + 1
+            // The screen keeps, per row-block pair, the running maximum of the lane's accumulators over ALL column blocks of the
+            // chunk: 16 three-input maxima per pair of tiles and nothing else (the compare, select and or of a per-tile test cost
+            // another 4 VALU instructions per 4 MFMAs, and the SIMD's issue port is what this loop is short of).  A candidate is
+            // then known up to its column block; the (rare) completion examines the lane's column in every block of the chunk.
+            int runmax[NRP];
+#pragma unroll
+            for (int p = 0; p < NRP; p++) runmax[p] = (int)0x80000000;
 #pragma unroll 1
-            for (int cb = 0; cb < CHUNK / 32; cb++) {
+            for (int cb = 0; cb < NCB; cb++) {
                 if (cbase + cb * 32 >= ncols) break;
                 v4i B[NF];
                 const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * NF * 16;
 #pragma unroll
                 for (int f = 0; f < NF; f++) B[f] = *reinterpret_cast<const v4i *>(bp + f * 16);
-                // max of the 32 accumulators of the two tiles in 16 instructions: a tree of 15 three-input maxima and one two-input
-                // one (depth 4).  A linear chain of dependent VALU instructions issues at ~9 clk each from one wave
+                // max of the 32 accumulators of the two tiles and the running maximum in 16 instructions: a tree of three-input
+                // maxima (depth 4).  A linear chain of dependent VALU instructions issues at ~9 clk each from one wave
                 // (tools/valu_dep.hip), independent ones at ~5.6.
-                auto max32 = [&](const Acc &x, const Acc &y) {
-                    const Scalar t0 = F::max3(x[0], x[1], x[2]), t1 = F::max3(x[3], x[4], x[5]), t2 = F::max3(x[6], x[7], x[8]);
-                    const Scalar t3 = F::max3(x[9], x[10], x[11]), t4 = F::max3(x[12], x[13], x[14]);
-                    const Scalar t5 = F::max3(y[0], y[1], y[2]), t6 = F::max3(y[3], y[4], y[5]), t7 = F::max3(y[6], y[7], y[8]);
-                    const Scalar t8 = F::max3(y[9], y[10], y[11]), t9 = F::max3(y[12], y[13], y[14]);
-                    const Scalar u0 = F::max3(t0, t1, t2), u1 = F::max3(t3, t4, x[15]), u2 = F::max3(t5, t6, t7), u3 = F::max3(t8, t9, y[15]);
-                    return F::max2(F::max3(u0, u1, u2), u3);
+                auto max33 = [&](const Acc &x, const Acc &y, int prev) {
+                    auto K = [](typename F::Scalar v) { return F::key(v); };
+                    const int t0 = max3i(K(x[0]), K(x[1]), K(x[2])), t1 = max3i(K(x[3]), K(x[4]), K(x[5])), t2 = max3i(K(x[6]), K(x[7]), K(x[8]));
+                    const int t3 = max3i(K(x[9]), K(x[10]), K(x[11])), t4 = max3i(K(x[12]), K(x[13]), K(x[14]));
+                    const int t5 = max3i(K(y[0]), K(y[1]), K(y[2])), t6 = max3i(K(y[3]), K(y[4]), K(y[5])), t7 = max3i(K(y[6]), K(y[7]), K(y[8]));
+                    const int t8 = max3i(K(y[9]), K(y[10]), K(y[11])), t9 = max3i(K(y[12]), K(y[13]), K(y[14]));
+                    const int u0 = max3i(t0, t1, t2), u1 = max3i(t3, t4, K(x[15])), u2 = max3i(t5, t6, t7), u3 = max3i(t8, t9, K(y[15]));
+                    return max3i(max3i(u0, u1, u2), u3, prev);
                 };
-                // One test for the two tiles of a chain pair, and no branch: the lane only sets bit (cb, rb / 2) of its candidate
-                // bitmap of the chunk.  (A branch here, however rare, stalls this wave's MFMA issue and, through the chunk
-                // barriers, its three block mates: 8e6 queue pushes cost 10 ms at threshold 40.)
                 // Two independent accumulation chains are interleaved (a dependent MFMA issues every ~55 clk, an independent one
-                // every 32: tools/mfma_rate.hip).
+                // every 32: tools/mfma_rate.hip).  No branch, compare or select in here: a branch, however rare, stalls this
+                // wave's MFMA issue and, through the chunk barriers, its three block mates.
 #pragma unroll
                 for (int rb = 0; rb < MF_RB; rb += 2) {
                     Acc acc0 = F::zero(), acc1 = F::zero();
@@ -485,8 +539,21 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
                         acc0 = F::mfma(A[rb][f], B[f], acc0);
                         acc1 = F::mfma(A[rb + 1][f], B[f], acc1);
                     }
-                    cand |= (max32(acc0, acc1) >= thresh_dot) ? (1u << (cb * (MF_RB / 2) + rb / 2)) : 0u;
+                    runmax[rb / 2] = max33(acc0, acc1, runmax[rb / 2]);
                 }
+            }
+            uint32_t cand = 0;  // bit p: this lane saw a candidate among its pairs of row blocks 2p, 2p + 1 in some column block of the chunk
+            if (ZO) {
+                // {0,1} encoding on popcount-sorted hashes: dot >= ceil((pa + pb - threshold) / 2) with the smallest pa of the 64 rows and
+                // the smallest pb of the chunk's columns
+#pragma unroll
+                for (int p = 0; p < NRP; p++) {
+                    const int need = (pa_min[p] + pb_min - (int)a.threshold + 1) >> 1;  // arithmetic shift = floor: ceil(x / 2) for any sign
+                    cand |= (runmax[p] >= F::thresh_key(need)) ? (1u << p) : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < NRP; p++) cand |= (runmax[p] >= thresh_key) ? (1u << p) : 0u;
             }
 
             // ---- lanes with candidates append (bitmap, column) to the wave's queue: slots by ballot rank, no atomics
@@ -510,20 +577,22 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
                 undrained = cend;
             } else if (nq >= 64 || cend == ncols) {
                 if (nq <= QCAP) {
-                    for (uint32_t t = lane; t < nq; t += 64) {
-                        const uint2 e = s_q[wave][t];
+                    // entries one after the other (wave-uniform), the lanes share the pairs of an entry: for every set bit the queued
+                    // lane's column in each of the NCB column blocks of its chunk against its 32 rows (C/D layout of the two tiles:
+                    // row = (r & 3) + 8 (r >> 2) + 4 h).  NCB * 32 items, two per lane and round so that their loads overlap.
+                    for (uint32_t t = 0; t < nq; t++) {
+                        const uint2 e = s_q[wave][t];  // same address in every lane: a broadcast read
                         const uint32_t eh = e.y >> 16;
                         uint32_t bm = e.x;
                         while (bm != 0) {
-                            const uint32_t bit = (uint32_t)__builtin_ctz(bm);
+                            const uint32_t rb = 2u * (uint32_t)__builtin_ctz(bm);
                             bm &= bm - 1;
-                            const uint32_t rb = 2u * (bit % (MF_RB / 2));
-                            const unsigned long long col = col0 + (e.y & 0xFFFFu) + 32u * (bit / (MF_RB / 2));
-                            // the 32 pairs of that lane: C/D layout of the two tiles: row = (r & 3) + 8 (r >> 2) + 4 h
-#pragma unroll 1
-                            for (uint32_t r = 0; r < 32; r++) {
+#pragma unroll
+                            for (uint32_t item = lane; item < (uint32_t)NCB * 32u; item += 64) {
+                                const uint32_t r = item & 31u, cb = item >> 5;
+                                const unsigned long long col = col0 + (e.y & 0xFFFFu) + 32u * cb;
                                 const unsigned long long owner = row0 + wrow + 32u * (rb + (r >> 4)) + (r & 3u) + 8u * ((r >> 2) & 3u) + 4u * eh;
-                                if (owner < a.n) complete(owner, col);
+                                if (owner < a.n && (e.y & 0xFFFFu) + 32u * cb < ncols) complete(owner, col);
                             }
                         }
                     }
@@ -631,11 +700,69 @@ extern "C" int rph_hamming_prefix_dwords(uint32_t threshold, int kernel)
             break;
         }
     }
-    if (kernel == 2 && (pw & 1)) pw++;
+    if (kernel >= 2 && (pw & 1)) pw++;
     return pw;
 }
 
-int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
+namespace {
+// ---- popcount sort of the hash array (for FmtFp4ZO) ----
+__global__ void __launch_bounds__(256) prefix_popcount_kernel(const uint32_t *__restrict__ hashes, unsigned long long n, int pw, uint16_t *keys, uint32_t *ids)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint4 lo = reinterpret_cast<const uint4 *>(hashes)[2 * i], hi = reinterpret_cast<const uint4 *>(hashes)[2 * i + 1];
+        const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t pc = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) pc += w < pw ? (uint32_t)__builtin_popcount(d[w]) : 0u;
+        keys[i] = (uint16_t)pc;
+        ids[i] = (uint32_t)i;
+    }
+}
+__global__ void __launch_bounds__(256) gather_hashes_kernel(const uint4 *__restrict__ hashes, const uint32_t *__restrict__ perm, unsigned long long n, uint4 *sorted)
+{
+    // thread = (sorted position, half of the hash)
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < 2 * n; t += (unsigned long long)gridDim.x * blockDim.x)
+        sorted[t] = hashes[2ull * perm[t >> 1] + (t & 1)];
+}
+constexpr unsigned long long ZO_MIN_N = 32768;  // below this the sort's launches cost more than the clock gain returns
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+}  // namespace
+
+// Sorted copy of the hashes + permutation + popcounts in the context's sweep scratch (stream ordered).  Stable radix sort: every
+// rank of a multi-GPU run builds the SAME order, so the part / nparts shares stay a partition of the pairs.
+static int prepare_sorted(rph_ctx *ctx, const uint8_t *d_hashes, uint64_t n, int pw, hipStream_t stream, SweepArgs &a)
+{
+    size_t temp_bytes = 0;
+    RPH_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const uint16_t *)nullptr, (uint16_t *)nullptr, (const uint32_t *)nullptr,
+                                                     (uint32_t *)nullptr, (int)n, 0, 9, stream));
+    const size_t o_sorted = 0, o_kin = o_sorted + align256(n * 32), o_kout = o_kin + align256(n * 2), o_iin = o_kout + align256(n * 2),
+                 o_iout = o_iin + align256(n * 4), o_temp = o_iout + align256(n * 4), need = o_temp + align256(temp_bytes);
+    if (ctx->sweep_scratch_bytes < need) {
+        RPH_HIP_CHECK(hipDeviceSynchronize());  // kernels of any stream may still be using the old scratch
+        if (ctx->sweep_scratch) RPH_HIP_CHECK(hipFree(ctx->sweep_scratch));
+        ctx->sweep_scratch = nullptr;
+        ctx->sweep_scratch_bytes = 0;
+        RPH_HIP_CHECK(hipMalloc(&ctx->sweep_scratch, need + need / 4));
+        ctx->sweep_scratch_bytes = need + need / 4;
+    }
+    if (!ctx->sweep_done) RPH_HIP_CHECK(hipEventCreateWithFlags(&ctx->sweep_done, hipEventDisableTiming));
+    if (ctx->sweep_used && ctx->sweep_stream != stream) RPH_HIP_CHECK(hipStreamWaitEvent(stream, ctx->sweep_done, 0));
+    uint8_t *base = (uint8_t *)ctx->sweep_scratch;
+    uint16_t *kin = (uint16_t *)(base + o_kin), *kout = (uint16_t *)(base + o_kout);
+    uint32_t *iin = (uint32_t *)(base + o_iin), *iout = (uint32_t *)(base + o_iout);
+    const unsigned grid = (unsigned)std::min<unsigned long long>((n + 255) / 256, 65536);
+    hipLaunchKernelGGL(prefix_popcount_kernel, dim3(grid), dim3(256), 0, stream, (const uint32_t *)d_hashes, n, pw, kin, iin);
+    RPH_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_temp, temp_bytes, kin, kout, iin, iout, (int)n, 0, 9, stream));
+    hipLaunchKernelGGL(gather_hashes_kernel, dim3((unsigned)std::min<unsigned long long>((2 * n + 255) / 256, 65536)), dim3(256), 0, stream,
+                       (const uint4 *)d_hashes, iout, n, (uint4 *)(base + o_sorted));
+    RPH_HIP_CHECK(hipGetLastError());
+    a.rows = a.cols = (const uint32_t *)(base + o_sorted);
+    a.perm = iout;
+    a.pcs = kout;
+    return RPH_OK;
+}
+
+int rph_launch_hamming_sweep(rph_ctx *ctx, const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
                              const uint8_t *d_has_features, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts, rph_edge *d_edges,
                              uint64_t cap, unsigned long long *d_count, hipStream_t stream, int use_mfma)
 {
@@ -670,13 +797,30 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
     a.edges = d_edges;
     a.cap = cap;
     a.count = d_count;
+    a.perm = nullptr;
+    a.pcs = nullptr;
     const unsigned long long mine = (a.n_tile_pairs > part) ? (a.n_tile_pairs - part + nparts - 1) / nparts : 0;
     if (mine == 0) return RPH_OK;
     const int pw = rph_hamming_prefix_dwords(a.threshold, use_mfma);
+    // plain all-pairs sweeps (rows are the columns, no per-file rules) run on popcount-sorted {0,1} operands
+    const bool zero_one = (use_mfma == 4 || (use_mfma == 2 && n >= ZO_MIN_N)) && ctx && n_variants == 1 && d_rows == d_cols && !d_low_conf && !d_has_features;
+    std::unique_lock<std::mutex> scratch_lock;
+    if (zero_one) {
+        scratch_lock = std::unique_lock<std::mutex>(ctx->mu);
+        int rc = prepare_sorted(ctx, d_cols, n, pw, stream, a);
+        if (rc != RPH_OK) return rc;
+    }
     for (unsigned long long b0 = 0; b0 < mine; b0 += MAX_GRID) {  // one launch carries at most MAX_GRID tile pairs
         a.block0 = b0;
         const dim3 grid((unsigned)((mine - b0) < MAX_GRID ? (mine - b0) : MAX_GRID)), block(BLOCK), mblock(MF_BLOCK);
-        if (use_mfma == 2) {
+        if (zero_one) {
+            if (pw == 4)
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtFp4ZO, 4>), grid, mblock, 0, stream, a);
+            else if (pw == 6)
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtFp4ZO, 6>), grid, mblock, 0, stream, a);
+            else
+                hipLaunchKernelGGL((hamming_mfma_kernel<FmtFp4ZO, 8>), grid, mblock, 0, stream, a);
+        } else if (use_mfma >= 2) {
             if (pw == 4)
                 hipLaunchKernelGGL((hamming_mfma_kernel<FmtFp4, 4>), grid, mblock, 0, stream, a);
             else if (pw == 6)
@@ -707,6 +851,11 @@ int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const u
                 hipLaunchKernelGGL(hamming_sweep_kernel<8>, grid, block, 0, stream, a);
         }
         RPH_HIP_CHECK(hipGetLastError());
+    }
+    if (zero_one) {  // later users of the sorted scratch on another stream wait for this sweep
+        RPH_HIP_CHECK(hipEventRecord(ctx->sweep_done, stream));
+        ctx->sweep_stream = stream;
+        ctx->sweep_used = true;
     }
     return RPH_OK;
 }

@@ -80,7 +80,7 @@ static int sweep_host(rph_ctx *ctx, const uint8_t *variants, uint32_t n_variants
     RPH_TRY(d_e.alloc(cap * sizeof(rph_edge)));
     RPH_TRY(d_cnt.alloc(8));
     RPH_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, 8, ctx->stream));
-    RPH_TRY(rph_launch_hamming_sweep(rows, n_variants, (const uint8_t *)d_h.p, (const uint8_t *)d_lc.p,
+    RPH_TRY(rph_launch_hamming_sweep(ctx, rows, n_variants, (const uint8_t *)d_h.p, (const uint8_t *)d_lc.p,
                                      (const uint8_t *)d_hf.p, n, thr, part, nparts, (rph_edge *)d_e.p, cap,
                                      (unsigned long long *)d_cnt.p, ctx->stream, ctx->hamming_kernel));
     unsigned long long cnt = 0;
@@ -185,6 +185,8 @@ int rph_shutdown(rph_ctx *ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->sink) (void)hipFree(ctx->sink);
     if (ctx->scratch_done) (void)hipEventDestroy(ctx->scratch_done);
+    if (ctx->sweep_scratch) (void)hipFree(ctx->sweep_scratch);
+    if (ctx->sweep_done) (void)hipEventDestroy(ctx->sweep_done);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RPH_OK;
@@ -212,7 +214,7 @@ void *rph_stream(rph_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int rph_hamming_set_kernel(rph_ctx *ctx, int which)
 {
-    if (!ctx || which < 0 || which > 2) return RPH_ERR_INVALID_ARG;
+    if (!ctx || which < 0 || which > 4) return RPH_ERR_INVALID_ARG;
     ctx->hamming_kernel = which;
     return RPH_OK;
 }
@@ -354,7 +356,7 @@ int rph_hamming_all_pairs_dev(rph_ctx *ctx, const void *d_hashes32, uint64_t n, 
         return RPH_ERR_INVALID_ARG;
     }
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
-    return rph_launch_hamming_sweep((const uint8_t *)d_hashes32, 1, (const uint8_t *)d_hashes32, nullptr, nullptr, n, threshold,
+    return rph_launch_hamming_sweep(ctx, (const uint8_t *)d_hashes32, 1, (const uint8_t *)d_hashes32, nullptr, nullptr, n, threshold,
                                     part, nparts, (rph_edge *)d_edges, cap, (unsigned long long *)d_count, pick(ctx, stream),
                                     ctx->hamming_kernel);
 }
@@ -368,7 +370,7 @@ int rph_hamming_variant_pairs_dev(rph_ctx *ctx, const void *d_variants, uint32_t
         return RPH_ERR_INVALID_ARG;
     }
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
-    return rph_launch_hamming_sweep((const uint8_t *)d_variants, n_variants, (const uint8_t *)d_hashes32,
+    return rph_launch_hamming_sweep(ctx, (const uint8_t *)d_variants, n_variants, (const uint8_t *)d_hashes32,
                                     (const uint8_t *)d_low_conf, nullptr, n, similarity, part, nparts, (rph_edge *)d_edges, cap,
                                     (unsigned long long *)d_count, pick(ctx, stream), ctx->hamming_kernel);
 }
@@ -687,6 +689,7 @@ int rph_stream_destroy(rph_ctx *ctx, void *stream)
     std::lock_guard<std::mutex> lock(ctx->mu);
     RPH_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     if (ctx->scratch_stream == (hipStream_t)stream) ctx->scratch_used = false;  // its work is complete: nothing left to order behind
+    if (ctx->sweep_stream == (hipStream_t)stream) ctx->sweep_used = false;
     RPH_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
     return RPH_OK;
 }

@@ -21,7 +21,15 @@ struct rph_ctx {
     hipEvent_t scratch_done = nullptr;
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
-    int hamming_kernel = 2;  // 2 = fp4 MFMA formulation of the sweep's fast path (default), 1 = int8 MFMA, 0 = VALU xor + popcount
+    // scratch of the popcount-sorted sweep (sorted hashes, permutation, popcounts, radix-sort workspace); same stream ordering rule
+    void *sweep_scratch = nullptr;
+    size_t sweep_scratch_bytes = 0;
+    hipEvent_t sweep_done = nullptr;
+    hipStream_t sweep_stream = nullptr;
+    bool sweep_used = false;
+    // 2 = fp4 MFMA formulation of the sweep's fast path, popcount-sorted {0,1} operands for plain all-pairs sweeps (default),
+    // 3 = fp4 MFMA with +-1 operands everywhere, 4 = sorted {0,1} at every size, 1 = int8 MFMA, 0 = VALU xor + popcount
+    int hamming_kernel = 2;
     int pdq_kernel = 1;  // 0 = always generic; 1 / 2 = fused 512x512x3 kernel (64- / 128-px strips) where it applies
 };
 
@@ -49,7 +57,7 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
                            uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream);
 int rph_launch_pdq_from_coeffs(const float *d_coeffs, uint32_t n, uint8_t *d_hash, uint8_t *d_dihedral, hipStream_t stream);
 // hamming_kernels.hip
-int rph_launch_hamming_sweep(const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
+int rph_launch_hamming_sweep(rph_ctx *ctx, const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
                              const uint8_t *d_has_features, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts, rph_edge *d_edges,
                              uint64_t cap, unsigned long long *d_count, hipStream_t stream, int use_mfma);
 int rph_launch_hamming64_sweep(const uint64_t *d_hashes, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts,

@@ -193,7 +193,9 @@ def test_dihedral_hashes_match_physically_transformed_image(eng, oracle):
 
 
 # ------------------------------------------------------------------ Hamming sweep
-@pytest.mark.parametrize("kernel", [2, 1, 0])  # 2 = fp4 MFMA fast path (default), 1 = int8 MFMA, 0 = VALU xor + popcount
+# 2 = fp4 MFMA fast path (default; +-1 operands below 32768 hashes), 4 = its popcount-sorted {0,1} form forced at every size,
+# 3 = fp4 +-1 forced, 1 = int8 MFMA, 0 = VALU xor + popcount
+@pytest.mark.parametrize("kernel", [2, 4, 3, 1, 0])
 @pytest.mark.parametrize("thr", [0, 10, 31, 32, 36, 40, 41, 48, 53, 54, 60, 66, 67, 74, 80, 81, 100, 200])
 def test_all_pairs_matches_brute_force(eng, oracle, thr, kernel):
     rng = np.random.default_rng(300 + thr)
@@ -211,14 +213,49 @@ def test_all_pairs_matches_brute_force(eng, oracle, thr, kernel):
         assert key(got) == key(other)
 
 
-def test_all_pairs_sharded_over_parts(eng, oracle):
+@pytest.mark.parametrize("kernel", [2, 4])
+def test_all_pairs_sharded_over_parts(eng, oracle, kernel):
     rng = np.random.default_rng(77)
     hashes = clustered_hashes(rng, 5000, 80, 40)
     want = sorted(map(tuple, oracle.all_pairs256(hashes, 32).tolist()))
-    for nparts in (2, 3, 8):
-        parts = [edge_set(eng.hamming_all_pairs(hashes, 32, part=p, nparts=nparts)) for p in range(nparts)]
-        merged = sorted(sum(parts, []))
-        assert merged == want and sum(len(p) for p in parts) == len(want)
+    eng.set_hamming_kernel(kernel)
+    try:
+        for nparts in (2, 3, 8):
+            parts = [edge_set(eng.hamming_all_pairs(hashes, 32, part=p, nparts=nparts)) for p in range(nparts)]
+            merged = sorted(sum(parts, []))
+            assert merged == want and sum(len(p) for p in parts) == len(want)
+    finally:
+        eng.set_hamming_kernel(2)
+
+
+@pytest.mark.parametrize("thr", [0, 3, 32, 40, 53, 64, 130])
+def test_sorted_zero_one_sweep_on_adversarial_popcounts(eng, oracle, thr):
+    """The {0,1} formulation thresholds on popcount(a) + popcount(b) - 2 popcount(a & b) with block-wise popcount minima of the
+    SORTED hashes: exercise prefixes of extreme and of widely spread popcount (sparse, dense, all-zero, all-one hashes, clusters that
+    straddle popcount steps), where the per-block bound is loosest, against the +-1 kernel, the VALU kernel and brute force."""
+    rng = np.random.default_rng(900 + thr)
+    n = 3000
+    dens = rng.choice([0.0, 0.02, 0.1, 0.3, 0.5, 0.7, 0.9, 0.98, 1.0], n)
+    bits = (rng.random((n, 256)) < dens[:, None]).astype(np.uint8)
+    hashes = np.packbits(bits, axis=1)
+    # near duplicates of sparse and dense hashes, and pairs that differ only OUTSIDE the 128-bit prefix
+    for k in range(0, 600, 3):
+        v = hashes[k].copy()
+        for b in rng.choice(256, int(rng.integers(0, thr + 6)), replace=False):
+            v[b >> 3] ^= 1 << (b & 7)
+        hashes[k + 1] = v
+        w = hashes[k].copy()
+        for b in rng.choice(np.arange(128, 256), int(rng.integers(0, min(thr + 6, 128))), replace=False):
+            w[b >> 3] ^= 1 << (b & 7)
+        hashes[k + 2] = w
+    want = sorted(map(tuple, oracle.all_pairs256(hashes, thr, cap=1 << 23).tolist()))
+    res = {}
+    for kernel in (4, 3, 0):
+        eng.set_hamming_kernel(kernel)
+        res[kernel] = sorted((int(x["i"]), int(x["j"]), int(x["d"]), int(x["flags"])) for x in eng.hamming_all_pairs(hashes, thr, cap=1 << 23))
+    eng.set_hamming_kernel(2)
+    assert [t[:3] for t in res[4]] == want
+    assert res[4] == res[3] == res[0]  # flags (find_groups reachability / probe slot) too
 
 
 @pytest.mark.parametrize("thr", [0, 40, 70])
@@ -352,7 +389,7 @@ def test_mih_build64_matches_reference_csr(eng, oracle):
 
 
 # ------------------------------------------------------------------ full-size, construction-known answers
-@pytest.mark.parametrize("kernel,n", [(2, 1_000_000), (1, 1_000_000), (0, 1_000_000), (2, 3_100_000), (1, 3_100_000)])
+@pytest.mark.parametrize("kernel,n", [(2, 1_000_000), (3, 1_000_000), (1, 1_000_000), (0, 1_000_000), (2, 3_100_000), (1, 3_100_000)])
 def test_one_million_hashes_threshold_32(eng, oracle, kernel, n):
     """BASELINE config 3: 1M synthetic hashes, 1000 injected 5-member clusters + the distance-32 pair.
     The expected edge set follows from the construction (random 256-bit pairs at d <= 32 have

@@ -35,11 +35,19 @@ while time.time() - t0 < budget:
         h[: min(n, int(rng.integers(64, 700)))] = h[0]
     nparts = int(rng.choice([1, 1, 2, 3, 5]))
     res = {}
-    for kern in (0, 1, 2):
+    if style == 2:  # skewed bit densities: the popcount-sorted {0,1} form thresholds on popcounts
+        dens = rng.choice([0.03, 0.2, 0.5, 0.8, 0.97], n)
+        h = np.packbits((rng.random((n, 256)) < dens[:, None]).astype(np.uint8), axis=1)
+        for j in range(1, n, 7):
+            v = h[j - 1].copy()
+            for b in rng.choice(256, int(rng.integers(0, min(thr + 3, 200))), replace=False):
+                v[b >> 3] ^= 1 << (b & 7)
+            h[j] = v
+    for kern in (0, 1, 3, 4):  # VALU, int8 MFMA, fp4 MFMA +-1, fp4 MFMA popcount-sorted {0,1}
         eng.set_hamming_kernel(kern)
         parts = [eng.hamming_all_pairs(h, thr, part=p, nparts=nparts, cap=max(1 << 16, 4 * n)) for p in range(nparts)]
         res[kern] = key(np.concatenate(parts))
-    assert res[0].shape == res[1].shape == res[2].shape and (res[0] == res[1]).all() and (res[0] == res[2]).all(), (n, thr, style, nparts)
+    assert all(res[0].shape == res[k].shape and (res[0] == res[k]).all() for k in (1, 3, 4)), (n, thr, style, nparts)
     cases += 1
 eng.set_hamming_kernel(2)
-print(f"seed {seed}: {cases} random cases, all three sweep formulations agree edge for edge")
+print(f"seed {seed}: {cases} random cases, all four sweep formulations agree edge for edge")

@@ -1,11 +1,20 @@
 #!/usr/bin/env python3
-"""one-line summary of a bench.py JSON line: `show_bench.py FILE [label]` (or `- label` to read stdin)"""
+"""tools/show_bench.py FILE... -- one line per bench.py JSON result"""
 import json
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "-"
-text = sys.stdin.read() if src == "-" else open(src).read()
-d = json.loads(text.strip().splitlines()[-1])
-h = d["hamming"]
-print(f"{sys.argv[2] if len(sys.argv) > 2 else ''} pdq {d['value']/1e6:.3f} M/s frac {d['roofline']['frac']:.3f} ({d['roofline']['kernel_ms']:.2f} ms, "
-      f"{d['config'].get('pdq_kernel')}) | hamming {h['value']:.0f} Gpairs/s ({h['roofline']['kernel_ms']:.2f} ms, edges {h['edges_found']}/{h['edges_expected']})")
+for path in sys.argv[1:]:
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    parts = [path.split("/")[-1]]
+    if d.get("value"):
+        r = d["roofline"]
+        parts.append(f"pdq {d['value'] / 1e6:.3f} M/s frac {r['frac']:.3f} ({r['kernel_ms']:.2f} ms, {d['config']['pdq_kernel']})")
+    if "e2e" in d:
+        e = d["e2e"]
+        parts.append(f"e2e {e['images_per_s'] / 1e6:.3f} M img/s ({e['seconds_per_run'] * 1e3:.1f} ms, {e['groups']} groups)")
+    if "hamming" in d:
+        h = d["hamming"]
+        parts.append(f"hamming thr {h['threshold']} {h['value']:.0f} Gpairs/s frac {h['roofline']['frac']:.3f} ({h['roofline']['kernel_ms']:.2f} ms, "
+                     f"PW {h['roofline']['prefix_dwords']}, edges {h['edges_found']}/{h['edges_expected']}, allgather {h['allgather_ms']:.2f} ms)")
+    parts.append(f"valid={d.get('valid')}")
+    print(" | ".join(parts))
