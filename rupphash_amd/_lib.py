@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librupphash_hip.so")
+# RPH_LIB_PATH: another build of the same library (A/B timing of kernel variants, tools/ab.sh); never a different implementation
+LIB_PATH = os.environ.get("RPH_LIB_PATH") or os.path.join(_HERE, "librupphash_hip.so")
 
 RPH_OK = 0
 RPH_ERR_INVALID_ARG = -1

@@ -328,10 +328,18 @@ __device__ __forceinline__ void half_build(Wave &w, int s, int h, const Row8 (&L
     wave_lds_fence();
 }
 
-// hs +/- (f16 half of a packed dword): v_fma_mix_f32 reads the f16 operand directly (no v_cvt); the sums are
-// exact integers, so the fused form cannot differ from cvt + add
+// The horizontal 8-window sum Hs advances by one column as Hs += V[x + 4] - V[x - 4].  The difference of the two f16 values is
+// exact (|d| <= 2040) and is formed for two columns at once (v_pk_add_f16 with a negated operand); v_fma_mix_f32 then adds one
+// half of it to the f32 sum, reading the f16 operand directly (no v_cvt).  All sums are exact integers, so this equals the direct
+// accumulation.  1.5 VALU instructions per column; the SIMD's VALU issue (85 % busy with two waves, profiles/) is what the kernel
+// is short of, so instruction COUNT is what matters here: the s_nop the compiler puts behind a high-half read (gfx950 op_sel
+// forwarding hazard) only delays the issuing wave, and its partner takes the slot.
+__device__ __forceinline__ uint32_t h2_diff(uint32_t cur, uint32_t prev)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, cur) - __builtin_bit_cast(h2, prev));
+}
 template <int HI>
-__device__ __forceinline__ float hs_add(float hs, uint32_t packed)
+__device__ __forceinline__ float hs_step(float hs, uint32_t packed)
 {
     float r;
     if (HI)
@@ -380,8 +388,7 @@ __device__ __forceinline__ void scan_strip(Wave &w)
 #pragma unroll
     for (int q = 0; q < G::NOCT; q++) {
         const uint4 cur = *reinterpret_cast<const uint4 *>(tp + 16 * q);
-        const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
-        const uint32_t pw[4] = {w.pv.x, w.pv.y, w.pv.z, w.pv.w};
+        const uint32_t dq[4] = {h2_diff(cur.x, w.pv.x), h2_diff(cur.y, w.pv.y), h2_diff(cur.z, w.pv.z), h2_diff(cur.w, w.pv.w)};
         const bool first_octet = FIRST && q == 0;
         float e0 = 0.f, e1 = 0.f, e2 = 0.f;
         if (first_octet) {  // pass-1 values of columns 0,1,2 come from the edge chains
@@ -391,8 +398,7 @@ __device__ __forceinline__ void scan_strip(Wave &w)
         }
 #define RPH_STEP(E)                                                              \
     {                                                                            \
-        w.hs = hs_add<(E) & 1>(w.hs, cw[(E) >> 1]);                              \
-        w.hs = hs_sub<(E) & 1>(w.hs, pw[(E) >> 1]);                              \
+        w.hs = hs_step<(E) & 1>(w.hs, dq[(E) >> 1]);                             \
         float in2 = pass1_value<EDGE_ROWS>(w, w.hs);                             \
         if (first_octet && (E) == 4) in2 = e0;                                   \
         if (first_octet && (E) == 5) in2 = e1;                                   \
