@@ -10,14 +10,16 @@
  * Conventions
  *   - every function returns 0 (RPH_OK) or a negative rph_status; nothing aborts
  *   - plain pointers and sizes only; the caller owns every buffer
- *   - one rph_ctx per process and GPU (one process per GPU; multi-GPU sharding is
- *     done by the caller's launcher, see rupphash_amd/dist.py); a context is
- *     thread-safe: calls on one context are serialised internally
+ *   - one rph_ctx per GPU (one process per GPU with rupphash_amd/dist.py, or several
+ *     contexts in one process under an rph_multi, below); a context is thread-safe:
+ *     concurrent calls are safe, their GPU work is ordered on the stream each one uses
+ *     (the context's own stream for the host-pointer entry points), and the library's
+ *     shared scratch buffers are handed from one stream to the next with events
  *   - `*_dev` twins take DEVICE pointers and a hipStream_t (as void*) and enqueue
  *     asynchronously on it (work given to different streams may overlap; the library
- *     orders its own shared scratch between them).  They do not synchronise, with one
- *     exception: rph_pdq_hash_batch_dev on images larger than 512 px allocates and frees
- *     its thumbnail buffers per call, and hipFree waits for the device.  Host-pointer
+ *     orders its own shared scratch between them).  They do not synchronise, except when
+ *     a scratch buffer has to grow or a source geometry larger than 512 px is met for
+ *     the first time (its resize tables are then uploaded once).  Host-pointer
  *     versions stage through device memory and return when the result is in the
  *     caller's buffer
  *   - there is no CPU fallback: if no gfx950 device is usable, rph_init fails
@@ -101,8 +103,10 @@ int rph_pdq_hash_batch_dev(rph_ctx *ctx, const void *d_px, uint32_t n, uint32_t 
 
 /*
  * generate_pdq_features for ONE image, as scanner.rs:1410 calls it from many rayon workers at once: thread-safe and
- * blocking; concurrent callers with the same geometry are coalesced into one GPU batch (the first caller of a batch
- * waits at most `max_wait_us` for others, default 256 images / 1000 us).  Same outputs as rph_pdq_hash_batch with n = 1.
+ * blocking; concurrent callers are coalesced into GPU batches (images of any mix of sizes) whose transfers are pipelined
+ * over three slots.  A batch goes as soon as nobody is still copying into it and a pipeline slot is free, so its size
+ * follows the load; `max_batch` (default 256) bounds it, `max_wait_us` (default 0) optionally holds a non-full batch back
+ * for more callers.  Same outputs as rph_pdq_hash_batch with n = 1.
  */
 int rph_pdq_hash_one(rph_ctx *ctx, const uint8_t *px, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride,
                      uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *valid_out);

@@ -1,69 +1,119 @@
 // batcher.cpp -- thread-safe single-image entry point with internal batching.
 //
 // The reference calls generate_pdq_features once per file from many rayon workers
-// (/root/reference/src/scanner.rs:1202-1205, :1410).  One image per GPU call would spend its time in launch and PCIe latency,
-// so concurrent callers are coalesced here: the first caller of a batch becomes its leader, waits until the batch is full or
-// `max_wait_us` has passed, runs ONE rph_pdq_hash_batch_dev over the pinned staging buffer and wakes the others.
-// Callers with a different geometry simply form their own batch.
+// (/root/reference/src/scanner.rs:1202-1205, :1410): blocking calls, one decoded image each, of whatever size the file had.
+// One image per GPU call would spend its time in launch and PCIe latency, so concurrent callers are coalesced here, and the
+// transfers of consecutive batches are pipelined:
+//
+//   * three pipeline slots, each with its own HIP stream, pinned host staging and device buffers; at most two batches are in
+//     flight (H2D of one overlaps the kernels / D2H of the other) while the third slot fills;
+//   * a caller joins the open batch and copies its pixels into the slot's pinned staging itself (outside the lock: the copies of
+//     different callers run in parallel on their own cores);
+//   * a batch goes as soon as nobody is still copying into it AND a pipeline slot is free -- no timer: under load the batch size
+//     adapts to the arrival rate (callers that arrive while two batches are in flight accumulate), an isolated caller is served at
+//     once.  `max_wait_us` (default 0) optionally holds a non-full batch back for more callers;
+//   * a batch takes at most half of the callers that were recently inside at once: blocking callers that all sit in ONE batch
+//     march in lockstep (copy, transfer, kernel, wake, copy, ...) and nothing overlaps; two half-size groups fall out of step after
+//     the first round and then one group copies while the other's pixels cross PCIe;
+//   * a batch may hold images of different geometry (a scan of mixed-size photos): they share the transfer and the
+//     synchronisation, and every run of consecutive images with one geometry is one rph_pdq_hash_batch_dev call on the slot's stream.
+// Whichever caller finds the batch ready becomes its leader, runs it and wakes the others.
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <map>
 #include <memory>
-#include <tuple>
 #include <vector>
 
 #include "rph_internal.h"
 
 namespace {
 
-// pinned host staging + device buffers of one batch; expensive to create (pinning ~200 MB takes tens of ms), so they are
-// pooled in the Batcher and reused by later batches of the same geometry
-struct Staging {
-    size_t image_bytes = 0;
-    uint32_t capacity = 0;
-    uint8_t *h_px = nullptr, *h_hash = nullptr, *h_valid = nullptr;
-    float *h_q = nullptr, *h_c = nullptr;
-    void *d_px = nullptr, *d_hash = nullptr, *d_q = nullptr, *d_c = nullptr, *d_v = nullptr;
-    bool alloc(size_t image_bytes_, uint32_t capacity_)
+constexpr int kSlots = 3;                          // pipeline depth: two in flight + one filling
+constexpr uint32_t kMaxInflight = 2;
+constexpr size_t kSlotPixelBytes = (size_t)128 << 20;  // pinned staging per slot (one larger image still gets a slot of its own size)
+constexpr uint32_t kSlotImages = 4096;             // result records per slot
+constexpr size_t kRecordBytes = 32 + 4 + 1 + 1024 + 16;  // hash, quality, valid, coefficients (+ alignment slack)
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    uint8_t *h_px = nullptr, *h_out = nullptr;  // pinned: pixels in, result records out
+    void *d_px = nullptr, *d_out = nullptr;
+    size_t px_cap = 0;
+    bool busy = false;  // owned by a batch (filling, in flight, or results still being read)
+
+    bool ensure(size_t px_bytes)
     {
-        image_bytes = image_bytes_;
-        capacity = capacity_;
-        return hipHostMalloc((void **)&h_px, image_bytes * capacity) == hipSuccess && hipHostMalloc((void **)&h_hash, (size_t)capacity * 32) == hipSuccess &&
-               hipHostMalloc((void **)&h_q, (size_t)capacity * 4) == hipSuccess && hipHostMalloc((void **)&h_c, (size_t)capacity * 1024) == hipSuccess &&
-               hipHostMalloc((void **)&h_valid, capacity) == hipSuccess && hipMalloc(&d_px, image_bytes * capacity) == hipSuccess &&
-               hipMalloc(&d_hash, (size_t)capacity * 32) == hipSuccess && hipMalloc(&d_q, (size_t)capacity * 4) == hipSuccess &&
-               hipMalloc(&d_c, (size_t)capacity * 1024) == hipSuccess && hipMalloc(&d_v, capacity) == hipSuccess;
+        if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        if (!h_out) {
+            if (hipHostMalloc((void **)&h_out, (size_t)kSlotImages * kRecordBytes) != hipSuccess || hipMalloc(&d_out, (size_t)kSlotImages * kRecordBytes) != hipSuccess)
+                return false;
+        }
+        if (px_cap < px_bytes) {  // only ever called on an idle slot
+            if (h_px) (void)hipHostFree(h_px);
+            if (d_px) (void)hipFree(d_px);
+            h_px = nullptr;
+            d_px = nullptr;
+            px_cap = 0;
+            if (hipHostMalloc((void **)&h_px, px_bytes) != hipSuccess || hipMalloc(&d_px, px_bytes) != hipSuccess) return false;
+            px_cap = px_bytes;
+        }
+        return true;
     }
-    ~Staging()
+    void release()
     {
-        for (void *p : {(void *)h_px, (void *)h_hash, (void *)h_valid, (void *)h_q, (void *)h_c})
+        for (void *p : {(void *)h_px, (void *)h_out})
             if (p) (void)hipHostFree(p);
-        for (void *p : {d_px, d_hash, d_q, d_c, d_v})
+        for (void *p : {d_px, d_out})
             if (p) (void)hipFree(p);
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+        *this = Slot();
     }
 };
 
-struct Batch {
+struct Item {
     uint32_t w, h, channels;
-    uint32_t capacity = 0, count = 0, copying = 0, readers = 0;
-    bool closed = false, done = false;
+    size_t off;  // byte offset of the packed image in the slot's staging
+};
+
+struct Batch {
+    Slot *slot = nullptr;
+    std::vector<Item> items;
+    size_t bytes = 0;
+    uint32_t copying = 0, readers = 0;
+    uint32_t cap = 1;      // images it accepts
+    bool want_coeffs = false;  // some caller asked for the coefficients (1 KB per image more on the way back)
+    // the results of n images come back in ONE transfer: [n x 32 hash][n x f32 quality][n valid][pad to 16][n x 1024 coefficients]
+    size_t o_q = 0, o_v = 0, o_c = 0;
+    bool closed = false;   // no further joins
+    bool running = false;  // a leader has taken it
+    bool done = false;
     int status = RPH_OK;
-    std::chrono::steady_clock::time_point born;
-    std::unique_ptr<Staging> st;
-    size_t image_bytes = 0;
-    std::condition_variable cv;
+    std::chrono::steady_clock::time_point last_join;
+    std::condition_variable cv;  // its callers wait here: done (all), or a chance to lead it (one)
 };
 
 struct Batcher {
     std::mutex mu;
-    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::shared_ptr<Batch>> open;  // batches still accepting images, by geometry
-    std::vector<std::unique_ptr<Staging>> pool;                                         // idle staging sets (at most kPoolMax)
+    std::condition_variable cv_slot;  // a slot became free
+    std::shared_ptr<Batch> open;
+    std::vector<std::shared_ptr<Batch>> live;  // batches that exist (<= kSlots): filling, waiting for the pipeline, in flight
+    Slot slots[kSlots];
+    uint32_t inflight = 0;
+    uint32_t inside = 0;    // callers currently in rph_pdq_hash_one
+    double crowd = 1.0;     // slowly decaying maximum of `inside`
     uint32_t max_batch = 256;
-    uint32_t max_wait_us = 1000;
+    uint32_t max_wait_us = 0;
     uint64_t n_batches = 0, n_images = 0;
+    ~Batcher()
+    {
+        for (Slot &s : slots) s.release();
+    }
 };
-constexpr size_t kPoolMax = 4;
 
 std::mutex g_registry_mu;
 std::map<rph_ctx *, std::unique_ptr<Batcher>> g_registry;
@@ -76,23 +126,36 @@ Batcher &batcher_of(rph_ctx *ctx)
     return *slot;
 }
 
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
 int run_batch(rph_ctx *ctx, Batch &b)
 {
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
-    const uint32_t n = b.count;
-    Staging &s = *b.st;
-    RPH_HIP_CHECK(hipMemcpyAsync(s.d_px, s.h_px, b.image_bytes * n, hipMemcpyHostToDevice, ctx->stream));
-    const int rc = rph_pdq_hash_batch_dev(ctx, s.d_px, n, b.w, b.h, b.channels, (size_t)b.w * b.channels, b.image_bytes, s.d_hash, s.d_q, s.d_c,
-                                          nullptr, s.d_v, ctx->stream);
-    if (rc != RPH_OK) {
-        (void)hipStreamSynchronize(ctx->stream);
-        return rc;
+    Slot &s = *b.slot;
+    const uint32_t n = (uint32_t)b.items.size();
+    b.o_q = (size_t)n * 32;
+    b.o_v = b.o_q + (size_t)n * 4;
+    b.o_c = align16(b.o_v + n);
+    uint8_t *d_out = (uint8_t *)s.d_out;
+    RPH_HIP_CHECK(hipMemcpyAsync(s.d_px, s.h_px, b.bytes, hipMemcpyHostToDevice, s.stream));
+    for (uint32_t first = 0; first < n;) {  // one launch sequence per run of equal geometry (packed back to back at a uniform stride)
+        const Item &a = b.items[first];
+        const size_t image_bytes = (size_t)a.w * a.h * a.channels, stride = align16(image_bytes);
+        uint32_t m = 1;
+        while (first + m < n && b.items[first + m].w == a.w && b.items[first + m].h == a.h && b.items[first + m].channels == a.channels &&
+               b.items[first + m].off == a.off + (size_t)m * stride)
+            m++;
+        const int rc = rph_pdq_hash_batch_dev(ctx, (const uint8_t *)s.d_px + a.off, m, a.w, a.h, a.channels, (size_t)a.w * a.channels, stride,
+                                              d_out + (size_t)first * 32, d_out + b.o_q + (size_t)first * 4,
+                                              b.want_coeffs ? d_out + b.o_c + (size_t)first * 1024 : nullptr, nullptr, d_out + b.o_v + first, s.stream);
+        if (rc != RPH_OK) {
+            (void)hipStreamSynchronize(s.stream);
+            return rc;
+        }
+        first += m;
     }
-    RPH_HIP_CHECK(hipMemcpyAsync(s.h_hash, s.d_hash, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    RPH_HIP_CHECK(hipMemcpyAsync(s.h_q, s.d_q, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    RPH_HIP_CHECK(hipMemcpyAsync(s.h_c, s.d_c, (size_t)n * 1024, hipMemcpyDeviceToHost, ctx->stream));
-    RPH_HIP_CHECK(hipMemcpyAsync(s.h_valid, s.d_v, n, hipMemcpyDeviceToHost, ctx->stream));
-    RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RPH_HIP_CHECK(hipMemcpyAsync(s.h_out, s.d_out, b.want_coeffs ? b.o_c + (size_t)n * 1024 : b.o_v + n, hipMemcpyDeviceToHost, s.stream));
+    RPH_HIP_CHECK(hipStreamSynchronize(s.stream));
     return RPH_OK;
 }
 
@@ -100,8 +163,16 @@ int run_batch(rph_ctx *ctx, Batch &b)
 
 void rph_batcher_forget(rph_ctx *ctx)
 {
-    std::lock_guard<std::mutex> lock(g_registry_mu);
-    g_registry.erase(ctx);
+    std::unique_ptr<Batcher> victim;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mu);
+        auto it = g_registry.find(ctx);
+        if (it != g_registry.end()) {
+            victim = std::move(it->second);
+            g_registry.erase(it);
+        }
+    }
+    if (victim) (void)hipSetDevice(ctx->device);  // the slots are released on this device by ~Batcher
 }
 
 extern "C" int rph_pdq_batcher_config(rph_ctx *ctx, uint32_t max_batch, uint32_t max_wait_us)
@@ -110,7 +181,7 @@ extern "C" int rph_pdq_batcher_config(rph_ctx *ctx, uint32_t max_batch, uint32_t
         if (!ctx || max_batch == 0 || max_batch > 65536) return RPH_ERR_INVALID_ARG;
         Batcher &B = batcher_of(ctx);
         std::lock_guard<std::mutex> lock(B.mu);
-        B.max_batch = max_batch;
+        B.max_batch = std::min(max_batch, kSlotImages);
         B.max_wait_us = max_wait_us;
         return RPH_OK;
     });
@@ -138,92 +209,117 @@ extern "C" int rph_pdq_hash_one(rph_ctx *ctx, const uint8_t *px, uint32_t w, uin
             return RPH_ERR_INVALID_ARG;
         }
         Batcher &B = batcher_of(ctx);
-        const auto key = std::make_tuple(w, h, channels);
+        const size_t line = (size_t)w * channels, image_bytes = line * h, need = align16(image_bytes);
         std::shared_ptr<Batch> b;
-        uint32_t slot;
-        bool leader = false;
-        {
-            std::unique_lock<std::mutex> lock(B.mu);
-            auto it = B.open.find(key);
-            if (it != B.open.end() && !it->second->closed && it->second->count < it->second->capacity) {
-                b = it->second;
-            } else {
-                b = std::make_shared<Batch>();
-                b->w = w;
-                b->h = h;
-                b->channels = channels;
-                b->image_bytes = (size_t)w * h * channels;
-                // keep a batch below ~256 MiB of pixels
-                const size_t by_bytes = std::max<size_t>(1, ((size_t)256 << 20) / b->image_bytes);
-                b->capacity = (uint32_t)std::min<size_t>(B.max_batch, by_bytes);
-                b->born = std::chrono::steady_clock::now();
-                for (size_t k = 0; k < B.pool.size(); k++)
-                    if (B.pool[k]->image_bytes == b->image_bytes && B.pool[k]->capacity == b->capacity) {
-                        b->st = std::move(B.pool[k]);
-                        B.pool.erase(B.pool.begin() + k);
-                        break;
-                    }
-                if (!b->st) {
-                    b->st.reset(new Staging());
-                    if (hipSetDevice(ctx->device) != hipSuccess || !b->st->alloc(b->image_bytes, b->capacity)) {
-                        rph_set_error("rph_pdq_hash_one: staging allocation failed (%zu bytes x %u)", b->image_bytes, b->capacity);
-                        return RPH_ERR_OOM;
-                    }
-                }
-                B.open[key] = b;
-                leader = true;
+        uint32_t slot_index = 0;
+        size_t off = 0;
+        std::unique_lock<std::mutex> lock(B.mu);
+        struct Inside {
+            Batcher &B;
+            explicit Inside(Batcher &b) : B(b)
+            {
+                B.inside++;
+                B.crowd = std::max((double)B.inside, B.crowd * 0.98);
             }
-            slot = b->count++;
-            b->copying++;
-            b->readers++;
-            if (b->count == b->capacity) b->cv.notify_all();  // wake the leader: batch is full
+            ~Inside() { B.inside--; }  // (runs with the lock held: every exit path below re-locks first)
+        } inside_guard(B);
+        // ---- join the open batch, or open one on a free slot
+        for (;;) {
+            if (B.open && !B.open->closed && B.open->items.size() < B.open->cap && B.open->bytes + need <= B.open->slot->px_cap) {
+                b = B.open;
+                break;
+            }
+            if (B.open && !B.open->closed) B.open->closed = true;  // full: it goes as soon as its copies are done and a slot is free
+            Slot *free_slot = nullptr;
+            for (Slot &s : B.slots)
+                if (!s.busy) {
+                    free_slot = &s;
+                    break;
+                }
+            if (free_slot) {
+                if (hipSetDevice(ctx->device) != hipSuccess || !free_slot->ensure(std::max(kSlotPixelBytes, need))) {
+                    rph_set_error("rph_pdq_hash_one: staging allocation failed (%zu bytes)", std::max(kSlotPixelBytes, need));
+                    return RPH_ERR_OOM;
+                }
+                free_slot->busy = true;
+                b = std::make_shared<Batch>();
+                b->slot = free_slot;
+                b->cap = std::min<uint32_t>(B.max_batch, std::max<uint32_t>(1, (uint32_t)((B.crowd + 1.0) / 2.0)));
+                b->items.reserve(b->cap);
+                B.open = b;
+                B.live.push_back(b);
+                break;
+            }
+            B.cv_slot.wait(lock);  // all slots taken: wait for one to come back
         }
-        // copy this caller's pixels into its slot (outside the lock: copies of different callers run in parallel)
+        slot_index = (uint32_t)b->items.size();
+        off = b->bytes;
+        b->items.push_back(Item{w, h, channels, off});
+        b->bytes += need;
+        b->copying++;
+        b->readers++;
+        b->last_join = std::chrono::steady_clock::now();
+        if (coeffs_out) b->want_coeffs = true;
+        if (b->items.size() >= b->cap) b->closed = true;
+        lock.unlock();
+        // ---- copy this caller's pixels into its place (outside the lock: copies of different callers run in parallel)
         {
-            uint8_t *dst = b->st->h_px + (size_t)slot * b->image_bytes;
-            const size_t line = (size_t)w * channels;
+            uint8_t *dst = b->slot->h_px + off;
             if (row_stride == line)
-                std::memcpy(dst, px, line * h);
+                std::memcpy(dst, px, image_bytes);
             else
                 for (uint32_t y = 0; y < h; y++) std::memcpy(dst + (size_t)y * line, px + (size_t)y * row_stride, line);
         }
-        {
-            std::unique_lock<std::mutex> lock(B.mu);
-            b->copying--;
-            if (leader) {
-                const auto deadline = b->born + std::chrono::microseconds(B.max_wait_us);
-                b->cv.wait_until(lock, deadline, [&] { return b->count == b->capacity; });
-                b->closed = true;
-                auto it = B.open.find(key);
-                if (it != B.open.end() && it->second == b) B.open.erase(it);  // later callers start a new batch
-                b->cv.wait(lock, [&] { return b->copying == 0; });            // every joined caller has finished copying
-                B.n_batches++;
-                B.n_images += b->count;
-                lock.unlock();
-                const int rc = run_batch(ctx, *b);
-                lock.lock();
-                b->status = rc;
-                b->done = true;
-                b->cv.notify_all();
-            } else {
-                b->cv.notify_all();  // the leader may be waiting for copying == 0
-                b->cv.wait(lock, [&] { return b->done; });
+        lock.lock();
+        b->copying--;
+        // ---- wait for the batch; whoever finds it ready to go runs it
+        while (!b->done) {
+            if (!b->running && b->copying == 0 && B.inflight < kMaxInflight) {
+                bool go = b->closed;  // a full batch goes at once
+                if (!go) {
+                    const auto linger_until = b->last_join + std::chrono::microseconds(B.max_wait_us);
+                    if (B.max_wait_us == 0 || std::chrono::steady_clock::now() >= linger_until)
+                        go = true;
+                    else {
+                        b->cv.wait_until(lock, linger_until);
+                        continue;
+                    }
+                }
+                if (go) {
+                    b->closed = true;
+                    b->running = true;
+                    if (B.open == b) B.open.reset();  // later callers start a new batch
+                    B.inflight++;
+                    B.n_batches++;
+                    B.n_images += b->items.size();
+                    lock.unlock();
+                    const int rc = run_batch(ctx, *b);
+                    lock.lock();
+                    b->status = rc;
+                    b->done = true;
+                    B.inflight--;
+                    b->cv.notify_all();
+                    for (auto &other : B.live)  // the pipeline has room again: one caller of every waiting batch gets to look
+                        if (other != b && !other->running) other->cv.notify_one();
+                    break;
+                }
             }
+            b->cv.wait(lock);
         }
         const int rc = b->status;
+        lock.unlock();
         if (rc == RPH_OK) {
-            const Staging &st = *b->st;
-            std::memcpy(hash32_out, st.h_hash + (size_t)slot * 32, 32);
-            if (quality_out) *quality_out = st.h_q[slot];
-            if (coeffs_out) std::memcpy(coeffs_out, st.h_c + (size_t)slot * 256, 1024);
-            if (valid_out) *valid_out = st.h_valid[slot];
+            const uint8_t *out = b->slot->h_out;
+            std::memcpy(hash32_out, out + (size_t)slot_index * 32, 32);
+            if (quality_out) std::memcpy(quality_out, out + b->o_q + (size_t)slot_index * 4, 4);
+            if (coeffs_out) std::memcpy(coeffs_out, out + b->o_c + (size_t)slot_index * 1024, 1024);
+            if (valid_out) *valid_out = out[b->o_v + slot_index];
         }
-        {
-            std::lock_guard<std::mutex> lock(B.mu);
-            if (--b->readers == 0) {  // last caller out: the staging set goes back to the pool
-                if (B.pool.size() >= kPoolMax) B.pool.erase(B.pool.begin());
-                B.pool.push_back(std::move(b->st));
-            }
+        lock.lock();
+        if (--b->readers == 0) {  // last caller out: the slot is free again
+            b->slot->busy = false;
+            B.live.erase(std::remove(B.live.begin(), B.live.end(), b), B.live.end());
+            B.cv_slot.notify_all();
         }
         return rc;
     });

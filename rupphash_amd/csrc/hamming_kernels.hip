@@ -346,7 +346,6 @@ struct FmtFp4 {  // +-1 as e2m1 (0x2 / 0xA): v_mfma_scale_f32_32x32x64_f8f6f4 at
 // prefix (one stable radix sort per call, rph_launch_hamming_sweep) pa is constant over a row block and pb over a column chunk up
 // to the few blocks that straddle a step, where the smaller value is used (never misses a pair; the completion is exact).
 struct FmtFp4ZO : FmtFp4 {
-    static constexpr bool ZERO_ONE = true;
     static __device__ __forceinline__ Lut lut_entry(uint32_t byte)
     {
         uint32_t e = 0;

@@ -148,7 +148,28 @@ __global__ void __launch_bounds__(64) from_coeffs_kernel(const float *__restrict
                             dihedral ? dihedral + (size_t)img * 256 : nullptr);
 }
 
+// files without features own their hash as the only variant (scanner.rs:1624-1627): every slot of such a file becomes its hash
+__global__ void __launch_bounds__(256) featureless_variants_kernel(const uint4 *__restrict__ hashes, const uint8_t *__restrict__ has_features, uint64_t n,
+                                                                   uint4 *variants)
+{
+    // thread = (file, slot, half of the 32-byte hash)
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * 16; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = t >> 4;
+        if (!has_features[i]) variants[t] = hashes[2 * i + (t & 1)];
+    }
+}
+
 }  // namespace
+
+int rph_launch_featureless_variants(const uint8_t *d_hashes, const uint8_t *d_has_features, uint64_t n, uint8_t *d_variants, hipStream_t stream)
+{
+    if (n == 0) return RPH_OK;
+    const uint64_t want = (n * 16 + 255) / 256;
+    hipLaunchKernelGGL(featureless_variants_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, stream, (const uint4 *)d_hashes, d_has_features, n,
+                       (uint4 *)d_variants);
+    RPH_HIP_CHECK(hipGetLastError());
+    return RPH_OK;
+}
 
 int rph_launch_pdq_from_coeffs(const float *d_coeffs, uint32_t n, uint8_t *d_hash, uint8_t *d_dihedral, hipStream_t stream)
 {

@@ -6,7 +6,10 @@
 // source is not part of the reference tree, so this is a statement of its published algorithm (Pillow-style
 // two-pass fixed-point convolution: f64 window weights -> i16 coefficients at an adaptive precision ->
 // clip8((round + sum) >> precision), horizontal pass into a u8 intermediate, then vertical).  PARITY UNPINNED.
+#include <algorithm>
 #include <cmath>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "rph_internal.h"
@@ -134,6 +137,68 @@ unsigned grid_for(uint64_t total) { return (unsigned)std::min<uint64_t>((total +
 
 }  // namespace
 
+// Device copies of the two coefficient tables of a source geometry, built once and kept in the context (a scan meets few
+// distinct geometries: the sizes its cameras produce).
+namespace {
+struct DevAxisOwner {
+    DevAxis ax{};
+    void *start = nullptr, *size = nullptr, *coef = nullptr;
+};
+struct AxisCache {
+    std::map<std::pair<uint32_t, uint32_t>, DevAxisOwner> axes;  // (in_size, out_size) -> tables
+};
+constexpr size_t kAxisCacheMax = 256;
+
+int device_axis(rph_ctx *ctx, uint32_t in_size, uint32_t out_size, DevAxis &out)
+{
+    if (!ctx->axis_cache) ctx->axis_cache = new AxisCache();
+    AxisCache &c = *static_cast<AxisCache *>(ctx->axis_cache);
+    auto it = c.axes.find({in_size, out_size});
+    if (it == c.axes.end()) {
+        if (c.axes.size() >= kAxisCacheMax) {  // rare: drop everything (kernels of any stream may still read the tables)
+            RPH_HIP_CHECK(hipDeviceSynchronize());
+            for (auto &kv : c.axes) {
+                (void)hipFree(kv.second.start);
+                (void)hipFree(kv.second.size);
+                (void)hipFree(kv.second.coef);
+            }
+            c.axes.clear();
+        }
+        const Axis a = build_axis(in_size, out_size);
+        DevAxisOwner o;
+        RPH_HIP_CHECK(hipMalloc(&o.start, a.start.size() * 4));
+        RPH_HIP_CHECK(hipMalloc(&o.size, a.size.size() * 4));
+        RPH_HIP_CHECK(hipMalloc(&o.coef, std::max<size_t>(a.coef.size(), 1) * 2));
+        RPH_HIP_CHECK(hipMemcpy(o.start, a.start.data(), a.start.size() * 4, hipMemcpyHostToDevice));  // synchronous: once per geometry
+        RPH_HIP_CHECK(hipMemcpy(o.size, a.size.data(), a.size.size() * 4, hipMemcpyHostToDevice));
+        RPH_HIP_CHECK(hipMemcpy(o.coef, a.coef.data(), a.coef.size() * 2, hipMemcpyHostToDevice));
+        o.ax = DevAxis{(const uint32_t *)o.start, (const uint32_t *)o.size, (const int16_t *)o.coef, a.window, a.precision};
+        it = c.axes.emplace(std::make_pair(in_size, out_size), o).first;
+    }
+    out = it->second.ax;
+    return RPH_OK;
+}
+}  // namespace
+
+void rph_resize_forget(rph_ctx *ctx)
+{
+    if (ctx->axis_cache) {
+        AxisCache *c = static_cast<AxisCache *>(ctx->axis_cache);
+        for (auto &kv : c->axes) {
+            (void)hipFree(kv.second.start);
+            (void)hipFree(kv.second.size);
+            (void)hipFree(kv.second.coef);
+        }
+        delete c;
+        ctx->axis_cache = nullptr;
+    }
+    if (ctx->rz_scratch) (void)hipFree(ctx->rz_scratch);
+    ctx->rz_scratch = nullptr;
+    ctx->rz_bytes = 0;
+}
+
+// Called with ctx->mu held (rph_pdq_hash_batch_dev).  Asynchronous on `stream`: nothing is allocated per call once the
+// geometry has been seen and the scratch has grown to the batch size, and nothing waits for the device.
 int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels,
                            size_t row_stride, size_t image_stride, uint8_t *d_hash, float *d_quality, float *d_coeffs,
                            uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream)
@@ -141,50 +206,39 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
     if (n == 0) return RPH_OK;
     uint32_t nw, nh;
     rph_pdq_target_dimensions(w, h, RPH_PDQ_MAX_DIM, &nw, &nh);  // pdqhash.rs:183
-    const Axis ax = build_axis(w, nw), ay = build_axis(h, nh);
-
-    // device copies of the two coefficient tables + per-chunk planes; this path is not the hot one: allocate per call
-    struct Buf {
-        void *p = nullptr;
-        ~Buf()
-        {
-            if (p) (void)hipFree(p);
-        }
-    } b_xs, b_xz, b_xc, b_ys, b_yz, b_yc, b_luma, b_tmp, b_small;
-    auto up = [&](Buf &b, const void *src, size_t bytes) -> int {
-        RPH_HIP_CHECK(hipMalloc(&b.p, bytes ? bytes : 1));
-        RPH_HIP_CHECK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, stream));
-        return RPH_OK;
-    };
+    DevAxis dx, dy;
     int rc;
-    if ((rc = up(b_xs, ax.start.data(), ax.start.size() * 4)) || (rc = up(b_xz, ax.size.data(), ax.size.size() * 4)) ||
-        (rc = up(b_xc, ax.coef.data(), ax.coef.size() * 2)) || (rc = up(b_ys, ay.start.data(), ay.start.size() * 4)) ||
-        (rc = up(b_yz, ay.size.data(), ay.size.size() * 4)) || (rc = up(b_yc, ay.coef.data(), ay.coef.size() * 2)))
-        return rc;
-    const DevAxis dx{(const uint32_t *)b_xs.p, (const uint32_t *)b_xz.p, (const int16_t *)b_xc.p, ax.window, ax.precision};
-    const DevAxis dy{(const uint32_t *)b_ys.p, (const uint32_t *)b_yz.p, (const int16_t *)b_yc.p, ay.window, ay.precision};
+    if ((rc = device_axis(ctx, w, nw, dx)) != RPH_OK || (rc = device_axis(ctx, h, nh, dy)) != RPH_OK) return rc;
 
-    const size_t full = (size_t)w * h;
+    const size_t full = (size_t)w * h, tmp = (size_t)nw * h, small = (size_t)nw * nh;
     uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)256 << 20) / full);
     chunk = std::min(chunk, n);
-    RPH_HIP_CHECK(hipMalloc(&b_luma.p, full * chunk));
-    RPH_HIP_CHECK(hipMalloc(&b_tmp.p, (size_t)nw * h * chunk));
-    RPH_HIP_CHECK(hipMalloc(&b_small.p, (size_t)nw * nh * chunk));
+    const size_t need = (full + tmp + small) * chunk;
+    if (ctx->rz_bytes < need) {
+        RPH_HIP_CHECK(hipDeviceSynchronize());  // kernels of any stream may still be using the old planes
+        if (ctx->rz_scratch) RPH_HIP_CHECK(hipFree(ctx->rz_scratch));
+        ctx->rz_scratch = nullptr;
+        ctx->rz_bytes = 0;
+        RPH_HIP_CHECK(hipMalloc((void **)&ctx->rz_scratch, need));
+        ctx->rz_bytes = need;
+    }
+    // the planes are shared by every caller stream, like the generic kernel's f32 planes, and are ordered by the same event
+    if (!ctx->scratch_done) RPH_HIP_CHECK(hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));
+    if (ctx->scratch_used && ctx->scratch_stream != stream) RPH_HIP_CHECK(hipStreamWaitEvent(stream, ctx->scratch_done, 0));
+    uint8_t *p_luma = ctx->rz_scratch, *p_tmp = p_luma + full * chunk, *p_small = p_tmp + tmp * chunk;
     for (uint32_t first = 0; first < n; first += chunk) {
         const uint32_t m = std::min(chunk, n - first);
         hipLaunchKernelGGL(luma_u8_kernel, dim3(grid_for((uint64_t)m * full)), dim3(256), 0, stream, d_px + (size_t)first * image_stride, m, w,
-                           h, channels, row_stride, image_stride, (uint8_t *)b_luma.p);
-        hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for((uint64_t)m * h * nw)), dim3(256), 0, stream, (const uint8_t *)b_luma.p,
-                           (uint8_t *)b_tmp.p, m, w, h, nw, dx);
-        hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((uint64_t)m * nh * nw)), dim3(256), 0, stream, (const uint8_t *)b_tmp.p,
-                           (uint8_t *)b_small.p, m, h, nw, nh, dy);
+                           h, channels, row_stride, image_stride, p_luma);
+        hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for((uint64_t)m * h * nw)), dim3(256), 0, stream, (const uint8_t *)p_luma, p_tmp, m, w, h, nw, dx);
+        hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((uint64_t)m * nh * nw)), dim3(256), 0, stream, (const uint8_t *)p_tmp, p_small, m, h, nw, nh, dy);
         RPH_HIP_CHECK(hipGetLastError());
-        // generate_pdq_from_luma on the thumbnail (no second size check in the reference: a 4000x5 input is hashed from 512x1)
-        rc = rph_launch_pdq_generic(ctx, (const uint8_t *)b_small.p, m, nw, nh, 1, nw, (size_t)nw * nh, d_hash + (size_t)first * 32,
+        // generate_pdq_from_luma on the thumbnail (no second size check in the reference: a 4000x5 input is hashed from 512x1).
+        // It records scratch_done on `stream` when it is through, which also covers the planes above.
+        rc = rph_launch_pdq_generic(ctx, (const uint8_t *)p_small, m, nw, nh, 1, nw, small, d_hash + (size_t)first * 32,
                                     d_quality ? d_quality + first : nullptr, d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr,
                                     d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr, d_valid ? d_valid + first : nullptr, stream);
         if (rc != RPH_OK) return rc;
     }
-    RPH_HIP_CHECK(hipStreamSynchronize(stream));  // the per-call buffers above are freed on return
     return RPH_OK;
 }

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "rph_internal.h"
@@ -123,6 +124,91 @@ static bool pdq_geometry_ok(uint32_t n, uint32_t w, uint32_t h, uint32_t channel
     return n <= 1 || image_stride >= row_stride * (h ? h - 1 : 0) + (size_t)w * channels;
 }
 
+// ---- staging pipe of rph_pdq_hash_batch ----
+namespace {
+constexpr size_t kPipeChunkBytes = (size_t)64 << 20;
+struct HostPipe {
+    hipStream_t stream[2] = {nullptr, nullptr};
+    uint8_t *h_px[2] = {nullptr, nullptr}, *h_hash[2] = {nullptr, nullptr}, *h_d[2] = {nullptr, nullptr}, *h_v[2] = {nullptr, nullptr};
+    float *h_q[2] = {nullptr, nullptr}, *h_c[2] = {nullptr, nullptr};
+    void *d_px[2] = {nullptr, nullptr}, *d_hash[2] = {nullptr, nullptr}, *d_q[2] = {nullptr, nullptr}, *d_c[2] = {nullptr, nullptr}, *d_d[2] = {nullptr, nullptr},
+         *d_v[2] = {nullptr, nullptr};
+    size_t px_bytes = 0;
+    uint32_t images = 0;
+    void release()
+    {
+        for (int b = 0; b < 2; b++) {
+            if (stream[b]) (void)hipStreamSynchronize(stream[b]);
+            for (void *p : {(void *)h_px[b], (void *)h_hash[b], (void *)h_d[b], (void *)h_v[b], (void *)h_q[b], (void *)h_c[b]})
+                if (p) (void)hipHostFree(p);
+            for (void *p : {d_px[b], d_hash[b], d_q[b], d_c[b], d_d[b], d_v[b]})
+                if (p) (void)hipFree(p);
+            if (stream[b]) (void)hipStreamDestroy(stream[b]);
+        }
+        *this = HostPipe();
+    }
+};
+
+int pipe_of(rph_ctx *ctx, size_t px_bytes, uint32_t images, HostPipe **out)
+{
+    if (!ctx->pipe) ctx->pipe = new HostPipe();
+    HostPipe &P = *static_cast<HostPipe *>(ctx->pipe);
+    if (P.px_bytes < px_bytes || P.images < images) {
+        const size_t nb = std::max(px_bytes, P.px_bytes);
+        const uint32_t ni = std::max(images, P.images);
+        P.release();
+        for (int b = 0; b < 2; b++) {
+            RPH_HIP_CHECK(hipStreamCreateWithFlags(&P.stream[b], hipStreamNonBlocking));
+            RPH_HIP_CHECK(hipHostMalloc((void **)&P.h_px[b], nb));
+            RPH_HIP_CHECK(hipMalloc(&P.d_px[b], nb));
+            RPH_HIP_CHECK(hipHostMalloc((void **)&P.h_hash[b], (size_t)ni * 32));
+            RPH_HIP_CHECK(hipHostMalloc((void **)&P.h_q[b], (size_t)ni * 4));
+            RPH_HIP_CHECK(hipHostMalloc((void **)&P.h_c[b], (size_t)ni * 1024));
+            RPH_HIP_CHECK(hipHostMalloc((void **)&P.h_d[b], (size_t)ni * 256));
+            RPH_HIP_CHECK(hipHostMalloc((void **)&P.h_v[b], ni));
+            RPH_HIP_CHECK(hipMalloc(&P.d_hash[b], (size_t)ni * 32));
+            RPH_HIP_CHECK(hipMalloc(&P.d_q[b], (size_t)ni * 4));
+            RPH_HIP_CHECK(hipMalloc(&P.d_c[b], (size_t)ni * 1024));
+            RPH_HIP_CHECK(hipMalloc(&P.d_d[b], (size_t)ni * 256));
+            RPH_HIP_CHECK(hipMalloc(&P.d_v[b], ni));
+        }
+        P.px_bytes = nb;
+        P.images = ni;
+    }
+    *out = &P;
+    return RPH_OK;
+}
+
+// pageable -> pinned with a few threads (one core moves ~10 GB/s, PCIe takes ~55)
+void parallel_copy(uint8_t *dst, const uint8_t *src, size_t bytes)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(8u, hw), bytes / ((size_t)4 << 20) + 1);
+    if (nt <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t part = ((bytes / nt) + 4095) & ~(size_t)4095;
+    for (unsigned t = 1; t < nt; t++) {
+        const size_t lo = std::min(bytes, part * t), hi = std::min(bytes, part * (t + 1));
+        if (hi > lo) th.emplace_back([=] { std::memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    std::memcpy(dst, src, std::min(bytes, part));
+    for (auto &x : th) x.join();
+}
+}  // namespace
+
+void rph_pipe_forget(rph_ctx *ctx)
+{
+    if (ctx->pipe) {
+        HostPipe *P = static_cast<HostPipe *>(ctx->pipe);
+        P->release();
+        delete P;
+        ctx->pipe = nullptr;
+    }
+}
+
 extern "C" {
 
 int rph_abi_version(void) { return RPH_ABI_VERSION; }
@@ -182,6 +268,8 @@ int rph_shutdown(rph_ctx *ctx)
     rph_batcher_forget(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    rph_pipe_forget(ctx);
+    rph_resize_forget(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->sink) (void)hipFree(ctx->sink);
     if (ctx->scratch_done) (void)hipEventDestroy(ctx->scratch_done);
@@ -280,34 +368,52 @@ int rph_pdq_hash_batch(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, 
             return RPH_ERR_INVALID_ARG;
         }
         RPH_HIP_CHECK(hipSetDevice(ctx->device));
-        // stage in chunks of <= 1 GiB of pixels
+        // Chunks of <= 64 MiB of pixels alternate between two staging sets (pinned host + device) and two streams: while chunk k
+        // crosses PCIe and is hashed, the host threads copy chunk k + 1 from the caller's (pageable) memory into the other pinned set.
         const size_t one_image = (size_t)(h ? h - 1 : 0) * row_stride + (size_t)w * channels;
         const size_t per = n > 1 ? image_stride : std::max<size_t>(one_image, 1);
-        uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / per);
-        chunk = std::min(chunk, n);
-        DevBuf d_px, d_hash, d_q, d_c, d_d, d_v;
-        RPH_TRY(d_px.alloc(per * chunk));
-        RPH_TRY(d_hash.alloc((size_t)chunk * 32));
-        if (quality_out) RPH_TRY(d_q.alloc((size_t)chunk * 4));
-        if (coeffs_out) RPH_TRY(d_c.alloc((size_t)chunk * 1024));
-        if (dihedral_out) RPH_TRY(d_d.alloc((size_t)chunk * 256));
-        if (valid_out) RPH_TRY(d_v.alloc(chunk));
-        for (uint32_t first = 0; first < n; first += chunk) {
+        const uint32_t chunk = (uint32_t)std::min<size_t>(n, std::max<size_t>(1, kPipeChunkBytes / per));
+        std::lock_guard<std::mutex> pipe_lock(ctx->pipe_mu);
+        HostPipe *P = nullptr;
+        RPH_TRY(pipe_of(ctx, per * (chunk - 1) + one_image, chunk, &P));
+        struct Pending {
+            uint32_t first = 0, m = 0;
+            bool active = false;
+        } pend[2];
+        auto finish = [&](int b) -> int {  // results of the chunk that used set b -> the caller's arrays
+            if (!pend[b].active) return RPH_OK;
+            RPH_HIP_CHECK(hipStreamSynchronize(P->stream[b]));
+            const uint32_t first = pend[b].first, m = pend[b].m;
+            std::memcpy(hash32_out + (size_t)first * 32, P->h_hash[b], (size_t)m * 32);
+            if (quality_out) std::memcpy(quality_out + first, P->h_q[b], (size_t)m * 4);
+            if (coeffs_out) std::memcpy(coeffs_out + (size_t)first * 256, P->h_c[b], (size_t)m * 1024);
+            if (dihedral_out) std::memcpy(dihedral_out + (size_t)first * 256, P->h_d[b], (size_t)m * 256);
+            if (valid_out) std::memcpy(valid_out + first, P->h_v[b], m);
+            pend[b].active = false;
+            return RPH_OK;
+        };
+        int k = 0;
+        for (uint32_t first = 0; first < n; first += chunk, k++) {
+            const int b = k & 1;
+            RPH_TRY(finish(b));
             const uint32_t m = std::min(chunk, n - first);
-            // the last image may be shorter than image_stride in the caller's buffer
-            const size_t bytes = (size_t)(m - 1) * per + one_image;
-            RPH_HIP_CHECK(hipMemcpyAsync(d_px.p, px + (size_t)first * per, bytes, hipMemcpyHostToDevice, ctx->stream));
-            RPH_TRY(rph_pdq_hash_batch_dev(ctx, d_px.p, m, w, h, channels, row_stride, per, d_hash.p, d_q.p, d_c.p, d_d.p, d_v.p,
-                                           ctx->stream));
-            RPH_HIP_CHECK(hipMemcpyAsync(hash32_out + (size_t)first * 32, d_hash.p, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->stream));
-            if (quality_out) RPH_HIP_CHECK(hipMemcpyAsync(quality_out + first, d_q.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
-            if (coeffs_out)
-                RPH_HIP_CHECK(hipMemcpyAsync(coeffs_out + (size_t)first * 256, d_c.p, (size_t)m * 1024, hipMemcpyDeviceToHost, ctx->stream));
-            if (dihedral_out)
-                RPH_HIP_CHECK(hipMemcpyAsync(dihedral_out + (size_t)first * 256, d_d.p, (size_t)m * 256, hipMemcpyDeviceToHost, ctx->stream));
-            if (valid_out) RPH_HIP_CHECK(hipMemcpyAsync(valid_out + first, d_v.p, m, hipMemcpyDeviceToHost, ctx->stream));
-            RPH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            const size_t bytes = (size_t)(m - 1) * per + one_image;  // the last image may be shorter than image_stride in the caller's buffer
+            parallel_copy(P->h_px[b], px + (size_t)first * per, bytes);
+            hipStream_t s = P->stream[b];
+            RPH_HIP_CHECK(hipMemcpyAsync(P->d_px[b], P->h_px[b], bytes, hipMemcpyHostToDevice, s));
+            RPH_TRY(rph_pdq_hash_batch_dev(ctx, P->d_px[b], m, w, h, channels, row_stride, per, P->d_hash[b], quality_out ? P->d_q[b] : nullptr,
+                                           coeffs_out ? P->d_c[b] : nullptr, dihedral_out ? P->d_d[b] : nullptr, valid_out ? P->d_v[b] : nullptr, s));
+            RPH_HIP_CHECK(hipMemcpyAsync(P->h_hash[b], P->d_hash[b], (size_t)m * 32, hipMemcpyDeviceToHost, s));
+            if (quality_out) RPH_HIP_CHECK(hipMemcpyAsync(P->h_q[b], P->d_q[b], (size_t)m * 4, hipMemcpyDeviceToHost, s));
+            if (coeffs_out) RPH_HIP_CHECK(hipMemcpyAsync(P->h_c[b], P->d_c[b], (size_t)m * 1024, hipMemcpyDeviceToHost, s));
+            if (dihedral_out) RPH_HIP_CHECK(hipMemcpyAsync(P->h_d[b], P->d_d[b], (size_t)m * 256, hipMemcpyDeviceToHost, s));
+            if (valid_out) RPH_HIP_CHECK(hipMemcpyAsync(P->h_v[b], P->d_v[b], m, hipMemcpyDeviceToHost, s));
+            pend[b].first = first;
+            pend[b].m = m;
+            pend[b].active = true;
         }
+        RPH_TRY(finish(k & 1));
+        RPH_TRY(finish((k + 1) & 1));
         return RPH_OK;
     });
 }
@@ -519,32 +625,65 @@ int rph_group_files_pdq(rph_ctx *ctx, const uint8_t *hashes32, const float *coef
         if (n < 2) return RPH_OK;
         RPH_HIP_CHECK(hipSetDevice(ctx->device));
 
+        // Everything between the caller's arrays and the edge list stays on the device: the hashes go up once, the 8 dihedral
+        // variants of every file are produced there from its coefficients (scanner.rs:1621-1623; the coefficients cross PCIe in
+        // 256 MiB pieces through a fixed staging buffer) and feed the variant sweep directly.
         std::vector<uint8_t> low_conf;
         if (quality) {
             low_conf.resize(n);
             for (uint64_t i = 0; i < n; i++) low_conf[i] = (uint8_t)rph_is_low_pdq_quality(quality[i]);
         }
-        // 8 dihedral variants per file from its coefficients (scanner.rs:1621-1623); files without
-        // features contribute their hash as the only variant (:1624-1627)
-        std::vector<uint8_t> variants;
+        hipStream_t s = ctx->stream;
+        DevBuf d_h, d_var, d_lc, d_hf, d_stage, d_e, d_cnt;
+        RPH_TRY(d_h.alloc(n * 32));
+        RPH_HIP_CHECK(hipMemcpyAsync(d_h.p, hashes32, n * 32, hipMemcpyHostToDevice, s));
+        if (quality) {
+            RPH_TRY(d_lc.alloc(n));
+            RPH_HIP_CHECK(hipMemcpyAsync(d_lc.p, low_conf.data(), n, hipMemcpyHostToDevice, s));
+        }
+        const bool use_hf = coeffs && has_features;
+        if (use_hf) {
+            RPH_TRY(d_hf.alloc(n));
+            RPH_HIP_CHECK(hipMemcpyAsync(d_hf.p, has_features, n, hipMemcpyHostToDevice, s));
+        }
         if (coeffs) {
-            variants.resize(n * 256);
-            const uint32_t step = 1u << 20;
+            RPH_TRY(d_var.alloc(n * 256));
+            const uint64_t step = 1u << 18;  // 256 MiB of coefficients per piece
+            RPH_TRY(d_stage.alloc(std::min<uint64_t>(step, n) * 1024));
             for (uint64_t first = 0; first < n; first += step) {
                 const uint32_t m = (uint32_t)std::min<uint64_t>(step, n - first);
-                RPH_TRY(rph_pdq_hashes_from_coeffs(ctx, coeffs + first * 256, m, nullptr, variants.data() + first * 256));
+                RPH_HIP_CHECK(hipMemcpyAsync(d_stage.p, coeffs + first * 256, (size_t)m * 1024, hipMemcpyHostToDevice, s));
+                RPH_TRY(rph_launch_pdq_from_coeffs((const float *)d_stage.p, m, nullptr, d_var.as<uint8_t>() + first * 256, s));
             }
-            if (has_features)
-                for (uint64_t i = 0; i < n; i++)
-                    if (!has_features[i])
-                        for (int v = 0; v < 8; v++) std::memcpy(&variants[i * 256 + v * 32], hashes32 + i * 32, 32);
+            if (use_hf) RPH_TRY(rph_launch_featureless_variants(d_h.as<uint8_t>(), d_hf.as<uint8_t>(), n, d_var.as<uint8_t>(), s));
         }
+        // Edge capacity: 32 per file to begin with (device memory is plentiful, 12 B each); a sweep that finds more is repeated
+        // once into a buffer of the size it reported.
         std::vector<rph_edge> edges;
-        RPH_TRY(sweep_growing(n, edges, [&](rph_edge *e, uint64_t cap, uint64_t *found) {
-            return sweep_host(ctx, coeffs ? variants.data() : nullptr, coeffs ? 8 : 1, hashes32,
-                              quality ? low_conf.data() : nullptr, (coeffs && has_features) ? has_features : nullptr, n, similarity,
-                              0, 1, e, cap, found);
-        }));
+        uint64_t cap = std::max<uint64_t>(1u << 20, 32 * n);
+        RPH_TRY(d_cnt.alloc(8));
+        for (int attempt = 0;; attempt++) {
+            RPH_TRY(d_e.alloc(cap * sizeof(rph_edge)));
+            RPH_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, 8, s));
+            RPH_TRY(rph_launch_hamming_sweep(ctx, coeffs ? d_var.as<uint8_t>() : d_h.as<uint8_t>(), coeffs ? 8 : 1, d_h.as<uint8_t>(), d_lc.as<uint8_t>(),
+                                             use_hf ? d_hf.as<uint8_t>() : nullptr, n, similarity, 0, 1, d_e.as<rph_edge>(), cap,
+                                             d_cnt.as<unsigned long long>(), s, ctx->hamming_kernel));
+            unsigned long long found = 0;
+            RPH_HIP_CHECK(hipMemcpyAsync(&found, d_cnt.p, 8, hipMemcpyDeviceToHost, s));
+            RPH_HIP_CHECK(hipStreamSynchronize(s));
+            if (found <= cap) {
+                edges.resize(found);
+                if (found) RPH_HIP_CHECK(hipMemcpy(edges.data(), d_e.p, found * sizeof(rph_edge), hipMemcpyDeviceToHost));
+                break;
+            }
+            if (attempt >= 2) {
+                rph_set_error("rph_group_files_pdq: edge list kept growing (%llu)", found);
+                return RPH_ERR_CAPACITY;
+            }
+            (void)hipFree(d_e.p);
+            d_e.p = nullptr;
+            cap = found + found / 16 + 1024;
+        }
         if (comparison_count_out) *comparison_count_out = edges.size();
         return rph_host_union_find(edges.data(), edges.size(), n, members, offsets, n_groups_out);
     });

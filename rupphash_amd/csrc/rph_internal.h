@@ -21,6 +21,16 @@ struct rph_ctx {
     hipEvent_t scratch_done = nullptr;
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
+    // rph_pdq_hash_batch (host pointers): two pinned staging sets + device twins, alternated over two streams so that the host
+    // copy / H2D of one chunk overlaps the transfer and kernels of the other (rph_api.cpp); one host-batch call at a time
+    std::mutex pipe_mu;
+    void *pipe = nullptr;
+    // pre-downsample (> 512 px inputs): u8 planes (full-resolution luma, horizontal pass, thumbnail) and the per-geometry
+    // coefficient tables, kept across calls; ordered between streams together with `scratch` (the generic kernel follows on the
+    // same stream and records scratch_done)
+    uint8_t *rz_scratch = nullptr;
+    size_t rz_bytes = 0;
+    void *axis_cache = nullptr;  // resize_kernels.hip
     // scratch of the popcount-sorted sweep (sorted hashes, permutation, popcounts, radix-sort workspace); same stream ordering rule
     void *sweep_scratch = nullptr;
     size_t sweep_scratch_bytes = 0;
@@ -56,6 +66,7 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
                            size_t row_stride, size_t image_stride, uint8_t *d_hash, float *d_quality, float *d_coeffs,
                            uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream);
 int rph_launch_pdq_from_coeffs(const float *d_coeffs, uint32_t n, uint8_t *d_hash, uint8_t *d_dihedral, hipStream_t stream);
+int rph_launch_featureless_variants(const uint8_t *d_hashes, const uint8_t *d_has_features, uint64_t n, uint8_t *d_variants, hipStream_t stream);
 // hamming_kernels.hip
 int rph_launch_hamming_sweep(rph_ctx *ctx, const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
                              const uint8_t *d_has_features, uint64_t n, uint32_t threshold, uint32_t part, uint32_t nparts, rph_edge *d_edges,
@@ -92,8 +103,12 @@ static inline int rph_guarded(const char *where, F &&body) noexcept
     }
 }
 
+// rph_api.cpp
+void rph_pipe_forget(rph_ctx *ctx);
 // batcher.cpp
 void rph_batcher_forget(rph_ctx *ctx);
+// resize_kernels.hip
+void rph_resize_forget(rph_ctx *ctx);
 
 // host_grouping.cpp
 int rph_host_union_find(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,

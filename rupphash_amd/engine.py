@@ -98,7 +98,7 @@ class Engine:
             return None
         return hash32, q.value, coeffs
 
-    def pdq_batcher_config(self, max_batch=256, max_wait_us=1000):
+    def pdq_batcher_config(self, max_batch=256, max_wait_us=0):
         check(self.L.rph_pdq_batcher_config(self.ctx, max_batch, max_wait_us), "rph_pdq_batcher_config")
 
     def pdq_batcher_stats(self):
