@@ -255,6 +255,42 @@ int rph_mih_build256(rph_ctx *ctx, const uint8_t *hashes32, uint64_t n, uint32_t
 int rph_mih_build64(rph_ctx *ctx, const uint64_t *hashes64, uint64_t n, uint32_t *offsets, uint32_t *values);
 
 /* =====================================================================
+ * Several GPUs under ONE host process  
+ *
+ * phdupes is a single process (scanner.rs:1146: one call hashes every file, then groups them), so the multi-GPU form of the
+ * path is offered inside the library: an rph_multi owns one rph_ctx per device and an RCCL communicator over them
+ * (ncclCommInitAll; RCCL is loaded at run time).  Its entry points shard exactly as rupphash_amd/dist.py does across processes:
+ * files are dealt to the devices in contiguous ranges (no communication), ONE ncclAllGather completes the per-file hash
+ * blocks on every device (the only exchange step of the path), every device sweeps the blocks p == i (mod n_devices) of the
+ * sweep's enumeration, the few edges go to the host for the serial union-find.  Results equal the single-context entry
+ * points for every n_devices.  One multi-device call at a time per rph_multi.
+ * ===================================================================== */
+typedef struct rph_multi rph_multi;
+/* devices: n_devices HIP ordinals, or NULL for 0 .. n_devices-1.  RPH_ERR_UNSUPPORTED when RCCL cannot be loaded. */
+int rph_multi_init(const int *devices, int n_devices, rph_multi **multi_out);
+int rph_multi_shutdown(rph_multi *multi);
+int rph_multi_size(rph_multi *multi);
+rph_ctx *rph_multi_ctx(rph_multi *multi, int index);  /* the context of device `index`: any single-device entry point works on it */
+/* rph_hamming_all_pairs across the devices (BASELINE config 5): hashes from the host, edges (unordered) back. */
+int rph_multi_hamming_all_pairs(rph_multi *multi, const uint8_t *hashes32, uint64_t n, uint32_t threshold, rph_edge *edges,
+                                uint64_t cap, uint64_t *n_edges_out);
+/*
+ * The reference's scan-then-group call (scanner.rs:1146-1551 + group_files_generic with PdqStrategy, :1640-1823) across the
+ * devices (BASELINE config 4): n images of one geometry in host memory -> PDQ hash, quality, coefficients (as
+ * rph_pdq_hash_batch; coeffs_out / quality_out / valid_out nullable) -> all-gather of the 8 dihedral hashes and the
+ * low-confidence flag of every file (quality = round(q * 100) < 50, scanner.rs:1416-1417, :1588-1594) -> variant sweep ->
+ * connected components as rph_group_files_pdq reports them.
+ */
+int rph_multi_hash_and_group(rph_multi *multi, const uint8_t *px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels,
+                             size_t row_stride, size_t image_stride, uint32_t similarity, uint8_t *hash32_out, float *quality_out,
+                             float *coeffs_out, uint8_t *valid_out, uint32_t *members, uint32_t *offsets, uint32_t *n_groups_out,
+                             uint64_t *comparison_count_out);
+/* rph_group_files_pdq across the devices: hashes / coefficients / quality from the cache (same arguments and results). */
+int rph_multi_group_files_pdq(rph_multi *multi, const uint8_t *hashes32, const float *coeffs, const uint8_t *has_features,
+                              const int32_t *quality, uint64_t n, uint32_t similarity, uint32_t *members, uint32_t *offsets,
+                              uint32_t *n_groups_out, uint64_t *comparison_count_out);
+
+/* =====================================================================
  * Cache record codecs (reference: src/db.rs), host scalar.  The layouts of the VALUES phdupes keeps per content hash,
  * for bulk import/export between an existing cache and the engine's flat arrays.  The XChaCha20-Poly1305 envelope
  * around them (db.rs:634-673) is the host application's business and is not touched here.

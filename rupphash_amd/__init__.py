@@ -11,6 +11,6 @@ include/rupphash.h); this package is the Python-side mirror of the reference's m
 There is no CPU fallback: every entry point needs the built library and a gfx950 device.
 """
 from ._lib import LIB_PATH, RphError, load  # noqa: F401
-from .engine import EDGE_DTYPE, Engine, default_engine  # noqa: F401
+from .engine import EDGE_DTYPE, Engine, MultiEngine, default_engine  # noqa: F401
 
-__all__ = ["Engine", "default_engine", "EDGE_DTYPE", "RphError", "LIB_PATH", "load"]
+__all__ = ["Engine", "MultiEngine", "default_engine", "EDGE_DTYPE", "RphError", "LIB_PATH", "load"]

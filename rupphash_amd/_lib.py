@@ -84,6 +84,15 @@ SIGNATURES = {
     "rph_is_low_pdq_quality": (C.c_int, [C.c_int32]),
     "rph_mih_build256": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, _u32p]),
     "rph_mih_build64": (C.c_int, [_vp, _u64p, C.c_uint64, _u32p, _u32p]),
+    "rph_multi_init": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "rph_multi_shutdown": (C.c_int, [_vp]),
+    "rph_multi_size": (C.c_int, [_vp]),
+    "rph_multi_ctx": (C.c_void_p, [_vp, C.c_int]),
+    "rph_multi_hamming_all_pairs": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "rph_multi_hash_and_group": (C.c_int, [_vp, _u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _sz, _sz, C.c_uint32, _u8p, _f32p, _f32p, _u8p,
+                                           _u32p, _u32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "rph_multi_group_files_pdq": (C.c_int, [_vp, _u8p, _f32p, _u8p, _i32p, C.c_uint64, C.c_uint32, _u32p, _u32p, C.POINTER(C.c_uint32),
+                                            C.POINTER(C.c_uint64)]),
     "rph_hash_record_encode": (None, [_u8p, _u8p]),
     "rph_hash_record_decode": (C.c_int, [_u8p, _sz, _u8p]),
     "rph_hash_records_encode": (None, [_u8p, _sz, _u8p]),

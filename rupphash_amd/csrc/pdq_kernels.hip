@@ -159,7 +159,27 @@ __global__ void __launch_bounds__(256) featureless_variants_kernel(const uint4 *
     }
 }
 
+// stored quality of scanner.rs:1416-1417, (q * 100).round().clamp(0, 100) as u16 (round half away from zero = roundf), against
+// PDQ_MIN_QUALITY (scanner.rs:1588-1594): 1 = low confidence.  Images that were not hashable (valid == 0) have no quality: not low.
+__global__ void __launch_bounds__(256) lowconf_kernel(const float *__restrict__ quality, const uint8_t *__restrict__ valid, uint64_t n, uint8_t *low)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        float stored = roundf(quality[i] * 100.0f);
+        stored = stored < 0.0f ? 0.0f : (stored > 100.0f ? 100.0f : stored);
+        low[i] = (uint8_t)((!valid || valid[i]) && stored < (float)RPH_PDQ_MIN_QUALITY);
+    }
+}
+
 }  // namespace
+
+int rph_launch_lowconf_from_quality(const float *d_quality, const uint8_t *d_valid, uint64_t n, uint8_t *d_low, hipStream_t stream)
+{
+    if (n == 0) return RPH_OK;
+    const uint64_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(lowconf_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, stream, d_quality, d_valid, n, d_low);
+    RPH_HIP_CHECK(hipGetLastError());
+    return RPH_OK;
+}
 
 int rph_launch_featureless_variants(const uint8_t *d_hashes, const uint8_t *d_has_features, uint64_t n, uint8_t *d_variants, hipStream_t stream)
 {

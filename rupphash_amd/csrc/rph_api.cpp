@@ -356,6 +356,18 @@ int rph_pdq_hash_batch(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, 
                        size_t row_stride, size_t image_stride, uint8_t *hash32_out, float *quality_out, float *coeffs_out,
                        uint8_t *dihedral_out, uint8_t *valid_out)
 {
+    return rph_pdq_hash_batch_keep(ctx, px, n, w, h, channels, row_stride, image_stride, hash32_out, quality_out, coeffs_out, dihedral_out, valid_out,
+                                   nullptr, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+// rph_pdq_hash_batch, optionally leaving device-resident copies of the per-image results behind (rph_multi: the hash blocks
+// go straight into the all-gather, multi.cpp).  d_*_keep: device arrays of n records on ctx's device, or nullptr.
+int rph_pdq_hash_batch_keep(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride,
+                            size_t image_stride, uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *dihedral_out,
+                            uint8_t *valid_out, void *d_hash_keep, void *d_quality_keep, void *d_dihedral_keep)
+{
     return rph_guarded("rph_pdq_hash_batch", [&]() -> int {
         if (!ctx || (!px && n) || !hash32_out) {
             rph_set_error("rph_pdq_hash_batch: null argument");
@@ -401,8 +413,13 @@ int rph_pdq_hash_batch(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, 
             parallel_copy(P->h_px[b], px + (size_t)first * per, bytes);
             hipStream_t s = P->stream[b];
             RPH_HIP_CHECK(hipMemcpyAsync(P->d_px[b], P->h_px[b], bytes, hipMemcpyHostToDevice, s));
-            RPH_TRY(rph_pdq_hash_batch_dev(ctx, P->d_px[b], m, w, h, channels, row_stride, per, P->d_hash[b], quality_out ? P->d_q[b] : nullptr,
-                                           coeffs_out ? P->d_c[b] : nullptr, dihedral_out ? P->d_d[b] : nullptr, valid_out ? P->d_v[b] : nullptr, s));
+            const bool want_q = quality_out || d_quality_keep, want_d = dihedral_out || d_dihedral_keep;
+            RPH_TRY(rph_pdq_hash_batch_dev(ctx, P->d_px[b], m, w, h, channels, row_stride, per, P->d_hash[b], want_q ? P->d_q[b] : nullptr,
+                                           coeffs_out ? P->d_c[b] : nullptr, want_d ? P->d_d[b] : nullptr, valid_out ? P->d_v[b] : nullptr, s));
+            if (d_hash_keep) RPH_HIP_CHECK(hipMemcpyAsync((uint8_t *)d_hash_keep + (size_t)first * 32, P->d_hash[b], (size_t)m * 32, hipMemcpyDeviceToDevice, s));
+            if (d_quality_keep) RPH_HIP_CHECK(hipMemcpyAsync((float *)d_quality_keep + first, P->d_q[b], (size_t)m * 4, hipMemcpyDeviceToDevice, s));
+            if (d_dihedral_keep)
+                RPH_HIP_CHECK(hipMemcpyAsync((uint8_t *)d_dihedral_keep + (size_t)first * 256, P->d_d[b], (size_t)m * 256, hipMemcpyDeviceToDevice, s));
             RPH_HIP_CHECK(hipMemcpyAsync(P->h_hash[b], P->d_hash[b], (size_t)m * 32, hipMemcpyDeviceToHost, s));
             if (quality_out) RPH_HIP_CHECK(hipMemcpyAsync(P->h_q[b], P->d_q[b], (size_t)m * 4, hipMemcpyDeviceToHost, s));
             if (coeffs_out) RPH_HIP_CHECK(hipMemcpyAsync(P->h_c[b], P->d_c[b], (size_t)m * 1024, hipMemcpyDeviceToHost, s));
@@ -417,6 +434,8 @@ int rph_pdq_hash_batch(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, 
         return RPH_OK;
     });
 }
+
+extern "C" {
 
 int rph_pdq_hashes_from_coeffs_dev(rph_ctx *ctx, const void *d_coeffs, uint32_t n, void *d_hash32, void *d_dihedral,
                                    void *stream)

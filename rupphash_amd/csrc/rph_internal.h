@@ -66,6 +66,7 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
                            size_t row_stride, size_t image_stride, uint8_t *d_hash, float *d_quality, float *d_coeffs,
                            uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream);
 int rph_launch_pdq_from_coeffs(const float *d_coeffs, uint32_t n, uint8_t *d_hash, uint8_t *d_dihedral, hipStream_t stream);
+int rph_launch_lowconf_from_quality(const float *d_quality, const uint8_t *d_valid, uint64_t n, uint8_t *d_low, hipStream_t stream);
 int rph_launch_featureless_variants(const uint8_t *d_hashes, const uint8_t *d_has_features, uint64_t n, uint8_t *d_variants, hipStream_t stream);
 // hamming_kernels.hip
 int rph_launch_hamming_sweep(rph_ctx *ctx, const uint8_t *d_rows, uint32_t n_variants, const uint8_t *d_cols, const uint8_t *d_low_conf,
@@ -105,6 +106,9 @@ static inline int rph_guarded(const char *where, F &&body) noexcept
 
 // rph_api.cpp
 void rph_pipe_forget(rph_ctx *ctx);
+int rph_pdq_hash_batch_keep(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride,
+                            size_t image_stride, uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *dihedral_out,
+                            uint8_t *valid_out, void *d_hash_keep, void *d_quality_keep, void *d_dihedral_keep);
 // batcher.cpp
 void rph_batcher_forget(rph_ctx *ctx);
 // resize_kernels.hip

@@ -348,3 +348,93 @@ def default_engine():
 
         _default = Engine(int(os.environ.get("LOCAL_RANK", "0")))
     return _default
+
+
+class MultiEngine:
+    """Several GPUs under this one process: an rph_multi (one rph_ctx per device + an RCCL communicator inside the library).
+    The sharded forms of the path (BASELINE configs 4 and 5) for a single-process host like the reference's scanner."""
+
+    def __init__(self, devices=None, n_devices=None):
+        self.L = _lib.load()
+        if devices is None:
+            devices = list(range(n_devices or 1))
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        check(self.L.rph_multi_init(arr, len(devices), C.byref(h)), "rph_multi_init")
+        self.m = h
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "m", None):
+            self.L.rph_multi_shutdown(self.m)
+            self.m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return self.L.rph_multi_size(self.m)
+
+    def engine(self, index):
+        """Engine view of device `index`'s context (owned by the multi: do not close it)"""
+        e = Engine.__new__(Engine)
+        e.L = self.L
+        e.ctx = None
+        ctx = self.L.rph_multi_ctx(self.m, index)
+        assert ctx
+        e.__dict__["ctx"] = C.c_void_p(ctx)
+        e.device = self.devices[index]
+        e.close = lambda: None
+        return e
+
+    def hamming_all_pairs(self, hashes, threshold, cap=None):
+        hashes = np.ascontiguousarray(hashes, np.uint8).reshape(-1, 32)
+        n = len(hashes)
+        cap = max(1 << 16, 4 * n) if cap is None else cap
+        while True:
+            edges = np.zeros(cap, EDGE_DTYPE)
+            found = C.c_uint64()
+            rc = self.L.rph_multi_hamming_all_pairs(self.m, _ptr(hashes), n, threshold, _ptr(edges), cap, C.byref(found))
+            if rc == _lib.RPH_ERR_CAPACITY:
+                cap = int(found.value) + 1024
+                continue
+            check(rc, "rph_multi_hamming_all_pairs")
+            return edges[: found.value]
+
+    def hash_and_group(self, images, similarity, want_coeffs=False):
+        """images: uint8 (n,h,w,3|4) or (n,h,w).  Returns dict(hash, quality, coeffs, valid, groups, comparison_count)."""
+        images = np.ascontiguousarray(images, np.uint8)
+        if images.ndim == 3:
+            n, h, w = images.shape
+            ch = 1
+        else:
+            n, h, w, ch = images.shape
+        out = {"hash": np.zeros((n, 32), np.uint8), "quality": np.zeros(n, np.float32),
+               "coeffs": np.zeros((n, 256), np.float32) if want_coeffs else None, "valid": np.zeros(n, np.uint8)}
+        members = np.zeros(max(n, 1), np.uint32)
+        offsets = np.zeros(n // 2 + 2, np.uint32)
+        ng = C.c_uint32()
+        cmp_count = C.c_uint64()
+        check(self.L.rph_multi_hash_and_group(self.m, _ptr(images), n, w, h, ch, w * ch, w * h * ch, similarity, _ptr(out["hash"]), _ptr(out["quality"]),
+                                              _ptr(out["coeffs"]), _ptr(out["valid"]), _ptr(members), _ptr(offsets), C.byref(ng), C.byref(cmp_count)),
+              "rph_multi_hash_and_group")
+        out["groups"] = Engine._groups(members, offsets, ng.value)
+        out["comparison_count"] = cmp_count.value
+        return out
+
+    def group_files_pdq(self, hashes, similarity, coeffs=None, has_features=None, quality=None):
+        hashes = np.ascontiguousarray(hashes, np.uint8).reshape(-1, 32)
+        n = len(hashes)
+        c = None if coeffs is None else np.ascontiguousarray(coeffs, np.float32).reshape(n, 256)
+        hf = None if has_features is None else np.ascontiguousarray(has_features, np.uint8)
+        q = None if quality is None else np.ascontiguousarray(quality, np.int32)
+        members = np.zeros(max(n, 1), np.uint32)
+        offsets = np.zeros(n // 2 + 2, np.uint32)
+        ng = C.c_uint32()
+        cmp_count = C.c_uint64()
+        check(self.L.rph_multi_group_files_pdq(self.m, _ptr(hashes), _ptr(c), _ptr(hf), _ptr(q), n, similarity, _ptr(members), _ptr(offsets),
+                                               C.byref(ng), C.byref(cmp_count)), "rph_multi_group_files_pdq")
+        return Engine._groups(members, offsets, ng.value), cmp_count.value

@@ -40,6 +40,48 @@ int main(void)
             if (rc != RPH_OK) { printf("grouping failed: %s\n", rph_last_error()); return 6; }
             printf("groups at distance <= 31: %u\n", ng);
         }
+        /* host-scalar forms (no context): PdqFeatures::to_hash of stored coefficients, cache records */
+        {
+            float coeffs[256];
+            uint8_t h2[32], rec[RPH_HASH_RECORD_BYTES], back[32];
+            int i;
+            for (i = 0; i < 256; i++) coeffs[i] = (float)((i * 37) % 101) - 50.0f;
+            rph_pdq_to_hash(coeffs, h2);
+            rph_hash_record_encode(h2, rec);
+            if (rec[0] != RPH_PDQ_ALGO_VERSION || rph_hash_record_decode(rec, sizeof rec, back) != 1 || memcmp(back, h2, 32) != 0) return 8;
+        }
     }
-    return rph_shutdown(ctx) == RPH_OK ? 0 : 7;
+    if (rph_shutdown(ctx) != RPH_OK) return 7;
+    /* Several GPUs under one process (here: the devices listed, one): the same groups as the single-context call */
+    {
+        enum { N = 600 };
+        static uint8_t hashes[N][32];
+        static float coeffs[N][256];
+        static int32_t quality[N];
+        static uint32_t m1[N], o1[N / 2 + 2], m2[N], o2[N / 2 + 2];
+        uint32_t g1 = 0, g2 = 0, x = 2463534242u;
+        uint64_t c1 = 0, c2 = 0;
+        rph_multi *multi = NULL;
+        int i, k;
+        for (i = 0; i < N; i++) {
+            for (k = 0; k < 256; k++) {
+                x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+                coeffs[i][k] = (i % 3 == 1) ? coeffs[i - 1][k] + (float)(x % 7) * 0.01f : (float)(x % 20001) / 100.0f - 100.0f;
+            }
+            quality[i] = (i % 50 == 7) ? 10 : 100;
+        }
+        rc = rph_multi_init(NULL, 1, &multi);
+        if (rc != RPH_OK) { printf("rph_multi_init failed: %s\n", rph_last_error()); return 9; }
+        if (rph_multi_size(multi) != 1 || rph_multi_ctx(multi, 0) == NULL) return 10;
+        for (i = 0; i < N; i++) rph_pdq_to_hash(coeffs[i], hashes[i]);
+        rc = rph_group_files_pdq(rph_multi_ctx(multi, 0), &hashes[0][0], &coeffs[0][0], NULL, quality, N, 40, m1, o1, &g1, &c1);
+        if (rc != RPH_OK) { printf("rph_group_files_pdq failed: %s\n", rph_last_error()); return 11; }
+        rc = rph_multi_group_files_pdq(multi, &hashes[0][0], &coeffs[0][0], NULL, quality, N, 40, m2, o2, &g2, &c2);
+        if (rc != RPH_OK) { printf("rph_multi_group_files_pdq failed: %s\n", rph_last_error()); return 12; }
+        printf("multi (%d device): %u groups, %lu comparisons; single context: %u groups, %lu comparisons\n", rph_multi_size(multi), g2,
+               (unsigned long)c2, g1, (unsigned long)c1);
+        if (g1 != g2 || c1 != c2 || g1 == 0 || memcmp(m1, m2, sizeof(uint32_t) * o1[g1]) != 0 || memcmp(o1, o2, sizeof(uint32_t) * (g1 + 1)) != 0) return 13;
+        if (rph_multi_shutdown(multi) != RPH_OK) return 14;
+    }
+    return 0;
 }

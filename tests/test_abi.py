@@ -156,3 +156,4 @@ def test_c_consumer_runs_on_gpu():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "distance between the two images" in r.stdout
+    assert "multi (1 device)" in r.stdout  # rph_multi at n_devices = 1: the same groups as rph_group_files_pdq

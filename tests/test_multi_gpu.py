@@ -1,0 +1,86 @@
+"""The in-library multi-GPU form (rph_multi: one context per device + an RCCL communicator, include/rupphash.h) on the devices
+this box has: with one device the all-gather is a one-rank collective and the sweep takes part 0 of 1 -- the same code path as
+with eight apart from the device count -- and every result must equal the single-context entry points."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def multi():
+    from rupphash_amd import MultiEngine
+
+    m = MultiEngine(n_devices=1)
+    yield m
+    m.close()
+
+
+def test_multi_context_is_a_working_engine(multi, oracle):
+    assert multi.size() == 1
+    eng = multi.engine(0)
+    name, cus, _ = eng.device_info()
+    assert "gfx950" in name and cus > 0
+    h = oracle.synth_hashes(0, 3000, 3000, n_clusters=20)
+    got = sorted((int(e["i"]), int(e["j"]), int(e["d"])) for e in eng.hamming_all_pairs(h, 32))
+    assert got == sorted(map(tuple, oracle.all_pairs256(h, 32).tolist()))
+
+
+@pytest.mark.parametrize("n,thr", [(5000, 32), (40001, 40), (2, 10)])
+def test_multi_all_pairs_equals_single_context(multi, oracle, n, thr):
+    h = oracle.synth_hashes(0, n, n, n_clusters=min(50, n // 10))
+    got = sorted((int(e["i"]), int(e["j"]), int(e["d"])) for e in multi.hamming_all_pairs(h, thr))
+    assert got == sorted(map(tuple, oracle.all_pairs256(h, thr).tolist()))
+
+
+def test_multi_hash_and_group_equals_oracle_production_grouping(multi, oracle):
+    first, n, sim = 900, 300, 32  # images 998/999 are a near-duplicate pair
+    imgs = oracle.synth_images(first, n)
+    res = multi.hash_and_group(imgs, sim, want_coeffs=True)
+    hashes, qual, coeffs = oracle.pdq_batch_rgb(imgs, want_coeffs=True)
+    assert np.array_equal(res["hash"], hashes) and res["valid"].all()
+    assert np.array_equal(res["coeffs"].view(np.uint32), coeffs.view(np.uint32))
+    assert np.array_equal(res["quality"].view(np.uint32), qual.view(np.uint32))
+    dih = np.stack([oracle.dihedral_hashes(c) for c in coeffs])
+    stored = np.clip(np.floor(qual * np.float32(100.0) + np.float32(0.5)), 0, 100).astype(np.int32)
+    edges, groups = oracle.group_pdq(hashes, sim, variants=dih, quality=stored)
+    assert res["groups"] == groups and res["comparison_count"] == len(edges)
+    assert [998 - first, 999 - first] in res["groups"]
+    # low-quality images pair only at distance 0 (scanner.rs:1699,1721): flat images have quality 0
+    flat = np.full((6, 512, 512, 3), 128, np.uint8)
+    flat[3:] += 1
+    r2 = multi.hash_and_group(flat, 10)
+    fh, fq, fc = oracle.pdq_batch_rgb(flat, want_coeffs=True)
+    e2, g2 = oracle.group_pdq(fh, 10, variants=np.stack([oracle.dihedral_hashes(c) for c in fc]), quality=np.zeros(6, np.int32))
+    assert r2["groups"] == g2 and r2["comparison_count"] == len(e2)
+    # too small to hash: every file is None, no groups (pdqhash.rs:167-169)
+    r3 = multi.hash_and_group(np.zeros((4, 4, 4, 3), np.uint8), 10)
+    assert not r3["valid"].any() and r3["groups"] == []
+
+
+@pytest.mark.parametrize("sim", [0, 31, 40, 63])
+def test_multi_group_files_pdq_equals_single_context(multi, oracle, sim):
+    rng = np.random.default_rng(50 + sim)
+    n = 4000
+    coeffs = rng.normal(0, 20, (n, 256)).astype(np.float32)
+    for k in range(0, 600, 3):  # near duplicates and rotated copies
+        coeffs[k + 1] = coeffs[k] + rng.normal(0, 0.4, 256).astype(np.float32)
+        c = coeffs[k].reshape(16, 16).T.copy()
+        coeffs[k + 2] = c.reshape(256)
+    has = (rng.random(n) > 0.1).astype(np.uint8)
+    quality = rng.choice([-1, 10, 49, 50, 100], n).astype(np.int32)
+    eng = multi.engine(0)
+    hashes, _ = eng.pdq_hashes_from_coeffs(coeffs, want_hash=True, want_dihedral=False)
+    want = eng.group_files_pdq(hashes, sim, coeffs=coeffs, has_features=has, quality=quality)
+    assert multi.group_files_pdq(hashes, sim, coeffs=coeffs, has_features=has, quality=quality) == want
+    assert multi.group_files_pdq(hashes, sim) == eng.group_files_pdq(hashes, sim)  # hashes only: one variant per file
+    dih = np.stack([oracle.dihedral_hashes(c) for c in coeffs])
+    e, g = oracle.group_pdq(hashes, sim, variants=dih, has_features=has, quality=quality)
+    assert want == (g, len(e))
+
+
+def test_multi_init_rejects_a_missing_device():
+    from rupphash_amd import MultiEngine, RphError
+
+    with pytest.raises(RphError):
+        MultiEngine(devices=[0, 99])
