@@ -120,3 +120,23 @@ void rph_ref_resize_box_u8(const uint8_t *src, uint32_t w, uint32_t h, uint8_t *
     axis_free(&ax);
     axis_free(&ay);
 }
+
+/* axis facts for the fixture tests: precision, window, and the smallest / largest sum of an output's coefficients
+ * (a normalised kernel sums to 1 << precision up to the rounding of its taps) */
+void rph_ref_resize_axis_info(uint32_t in_size, uint32_t out_size, int *precision, int *window, int32_t *sum_min, int32_t *sum_max)
+{
+    axis_t a;
+    axis_build(&a, in_size, out_size);
+    int32_t lo = INT32_MAX, hi = INT32_MIN;
+    for (uint32_t o = 0; o < out_size; o++) {
+        int32_t s = 0;
+        for (uint32_t i = 0; i < a.size[o]; i++) s += a.coef[(size_t)o * a.window + i];
+        if (s < lo) lo = s;
+        if (s > hi) hi = s;
+    }
+    *precision = a.precision;
+    *window = a.window;
+    *sum_min = lo;
+    *sum_max = hi;
+    axis_free(&a);
+}

@@ -212,6 +212,9 @@ def engine_fns(eng, semantics="union_find"):
 # ---------------------------------------------------------------------------------------------------------------------
 # Device-resident form of the whole path (BASELINE config 4), production grouping semantics
 # ---------------------------------------------------------------------------------------------------------------------
+_side_streams = {}
+
+
 def stored_quality_lowconf(quality):
     """quality in [0,1] (device tensor) -> uint8 low-confidence flags: round(q * 100) clamped to 0..100 (scanner.rs:1416-1417,
     round half away from zero) < PDQ_MIN_QUALITY (scanner.rs:1588-1594)"""
@@ -239,10 +242,22 @@ def hash_and_group_device(eng, images, n_total, similarity, dist=None, variants=
 
     import torch
 
+    dev = images.device
+    caller = torch.cuda.current_stream(dev)
+    if caller.cuda_stream == 0:
+        # The library takes a null stream handle to mean "the context's own stream", which the legacy default stream does not
+        # order with: run on an explicit side stream instead, entered behind the caller's work and joined again at the end.
+        side = _side_streams.get(dev)
+        if side is None:
+            side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(caller)
+        with torch.cuda.stream(side):
+            out = hash_and_group_device(eng, images, n_total, similarity, dist, variants, w, h, channels, edge_cap, timings)
+        caller.wait_stream(side)
+        return out
     world = 1 if dist is None else dist.get_world_size()
     rank = 0 if dist is None else dist.get_rank()
-    dev = images.device
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = caller.cuda_stream
     lo, hi = shard_range(n_total, rank, world)
     n_local = hi - lo
     assert images.shape[0] == n_local, (images.shape, lo, hi)

@@ -201,6 +201,13 @@ def resize_box_u8(luma, nw, nh):
     return out
 
 
+def resize_axis_info(in_size, out_size):
+    """(precision, window, min coefficient sum, max coefficient sum) of one axis of the box pre-downsample"""
+    p, w, lo, hi = C.c_int(), C.c_int(), C.c_int32(), C.c_int32()
+    lib().rph_ref_resize_axis_info(C.c_uint32(in_size), C.c_uint32(out_size), C.byref(p), C.byref(w), C.byref(lo), C.byref(hi))
+    return p.value, w.value, lo.value, hi.value
+
+
 def jarosz(plane, w_rows, w_cols, nreps=2):
     buf = np.array(plane, np.float32, copy=True, order="C")
     tmp = np.zeros_like(buf)
