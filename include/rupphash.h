@@ -127,9 +127,11 @@ int rph_pdq_hashes_from_coeffs_dev(rph_ctx *ctx, const void *d_coeffs, uint32_t 
 void rph_pdq_to_hash(const float *coeffs256, uint8_t *hash32_out);
 void rph_pdq_dihedral_one(const float *coeffs256, uint8_t *out8x32);
 
-/* Which PDQ kernel a context uses for 512x512 RGB8: 0 = generic multi-pass (any geometry), 1 = fused single-pass
- * with 64-px strips (default: 8 waves per CU, fastest), 2 = fused with 128-px strips (cache-line aligned loads,
- * 6 waves per CU).  All three produce identical bits.  Debug/bench. */
+/* Which PDQ kernel a context uses for 512x512 RGB8: 0 = generic multi-pass (any geometry), 1 = fused single-pass, one wave
+ * per image, 64-px strips (8 waves per CU: the throughput kernel, ~0.3 ms per image however few there are), 2 = the same
+ * with 128-px strips (cache-line aligned loads, 6 waves per CU), 3 = fused low-latency form (eight waves share an image:
+ * ~60 us, one image per CU), 4 = automatic (default): 3 below 768 images per call, 1 from there.  All produce identical
+ * bits.  Debug/bench. */
 int rph_pdq_set_kernel(rph_ctx *ctx, int which);
 
 /* calculate_target_dimensions (pdqhash.rs:224-235): integer geometry, host. */

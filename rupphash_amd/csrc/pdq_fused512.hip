@@ -581,11 +581,26 @@ __device__ __forceinline__ void edge_band(Wave &w, int b)
     wave_lds_fence();
 }
 
-template <class G, int KIND>
-__device__ __forceinline__ void do_band(Wave &w, int b, Px8 (&pre)[8])
+// Low-latency form: where the samples of a half band go instead of into this wave's column chain ([slot 0..64][row 0..63] floats
+// of band b in the image's sample scratch; slot k holds sampled column k - 1, slot 0 is the dummy)
+template <class G>
+__device__ __forceinline__ void store_samples(const Wave &w, float *band_samples, bool second_half)
+{
+    float *p = band_samples + (second_half ? 32 * 64 : 0) + w.lane;
+    asm volatile("" : "+v"(p));  // the 33 store addresses are formed here, from this one pointer (hoisted out of the strip loop they are 66 live VGPRs)
+#pragma unroll
+    for (int t = 0; t < 32; t++) p[t * 64] = w.smp[t];
+    if (second_half) p[32 * 64] = w.smp_last;
+}
+
+// LL = false: the band of a wave that walks the whole image (edge chains, column chain and tail carried from band to band).
+// LL = true: the band of one of the eight waves that share an image (pdq_fused512_ll_kernel): the edge values of the band are already
+// in the wave's edge area, the prefetch stops at the band's end, and the pass-2 row samples go to `samples` for the final chain.
+template <class G, int KIND, bool LL = false>
+__device__ __forceinline__ void do_band(Wave &w, int b, Px8 (&pre)[8], float *samples = nullptr)
 {
     constexpr bool EDGE_ROWS = KIND != 1;
-    edge_band<G, KIND>(w, b);
+    if (!LL) edge_band<G, KIND>(w, b);
     scan_reset(w, b);
 #pragma unroll 1
     for (int s = 0; s < G::NSTRIP; s++) {
@@ -602,7 +617,7 @@ __device__ __forceinline__ void do_band(Wave &w, int b, Px8 (&pre)[8])
                     nb = b + 1;
                 }
             }
-            half_luma<G, KIND == 2>(w, b, h, pre, L, nb < 8, nb, ns, nh);
+            half_luma<G, KIND == 2>(w, b, h, pre, L, LL ? nb == b : nb < 8, nb, ns, nh);
             half_build<G>(w, s, h, L);
         }
         if (s == 0)
@@ -612,10 +627,16 @@ __device__ __forceinline__ void do_band(Wave &w, int b, Px8 (&pre)[8])
         else
             scan_strip<G, EDGE_ROWS, false, false>(w);
         wave_lds_fence();
-        if (s == G::NSTRIP / 2 - 1) col_pass<G>(w, b, false);
-        if (s == G::NSTRIP - 1) col_pass<G>(w, b, true);
+        if (LL) {
+            if (s == G::NSTRIP / 2 - 1) store_samples<G>(w, samples, false);
+            if (s == G::NSTRIP - 1) store_samples<G>(w, samples, true);
+        } else {
+            if (s == G::NSTRIP / 2 - 1) col_pass<G>(w, b, false);
+            if (s == G::NSTRIP - 1) col_pass<G>(w, b, true);
+        }
         wave_lds_fence();
     }
+    if (LL) return;
     // band b completed decimated rows i = 8 b + u - 1 (u = 0 of band 0 is a dummy): feed them to the tail in order
 #pragma unroll
     for (int u = 0; u < 8; u++)
@@ -679,13 +700,209 @@ __global__ void __launch_bounds__(64, G::WAVES_PER_SIMD) pdq_fused512_kernel(con
     if (valid && w.lane == 0) valid[img] = 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Low-latency form: eight waves share an image, one band each.
+//
+// The kernel above gives an image to one wave: ~0.3 ms from its first byte to its hash, which is fine when thousands of images
+// are in flight and is the whole cost when a handful are (the one-image-per-call queue, batcher.cpp).  Here a workgroup of eight
+// waves takes an image; wave b runs band b with the same code.  What is sequential across bands is cut out and done cheaply:
+//   * the 7 luma rows above a band: every wave recomputes them from the image (7 rows = 1.4 % of the pixels);
+//   * the six edge chains (pass-1 column recurrence of the frame columns): all waves compute their band's chain INPUTS into a
+//     shared table, then wave b runs the recurrence from row 0 to its own band (2 instructions per row for the part above);
+//   * the pass-2 column chain and the tail: the waves leave their row samples in a scratch buffer (133 KB per image, L2
+//     resident), and wave 0 runs the chain over all 512 rows at the end.
+// Same bits as the other kernels (tests/test_gpu_parity.py forces each).  ~60 us per image, one image per CU at a time.
+// ---------------------------------------------------------------------------------------------
+constexpr int LL_SAMPLE_FLOATS = 8 * 65 * 64;  // per image: [band][slot][row]
+constexpr int LL_EDGE_PITCH = 520;             // chain inputs of rows 0..515 (512..515: nothing enters)
+
+template <class G, int KIND>
+__device__ __forceinline__ void ll_band(Wave &w, int b, float *samples)
+{
+    Px8 pre[8];
+    half_issue<G>(w, b, 0, 0, pre);
+    do_band<G, KIND, true>(w, b, pre, samples);
+}
+
+template <class G>
+__global__ void __launch_bounds__(512, 2) pdq_fused512_ll_kernel(const uint8_t *__restrict__ px, uint32_t n, size_t row_stride, size_t image_stride,
+                                                                 float *__restrict__ sample_scratch, uint8_t *hash, float *quality, float *coeffs,
+                                                                 uint8_t *dihedral, uint8_t *valid)
+{
+    static_assert(G::NH == 1, "the low-latency kernel is built on the 64-px strip geometry");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[8 * G::LDS_BYTES + 6 * LL_EDGE_PITCH * 4];
+    const uint32_t img = blockIdx.x;
+    const int band = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and known to the compiler as such (scalar branches, scalar addresses)
+    Wave w;
+    w.lds = lds + band * G::LDS_BYTES;
+    w.img = px + (size_t)img * image_stride;
+    w.row_stride = row_stride;
+    w.rs32 = (uint32_t)row_stride;
+    w.lane = threadIdx.x & 63;
+    w.smp_last = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; i++) w.smp[i] = 0.f;
+    w.want_quality = quality != nullptr;
+    float *edge_all = reinterpret_cast<float *>(lds + 8 * G::LDS_BYTES);
+    float *samples = sample_scratch + (size_t)img * LL_SAMPLE_FLOATS;
+
+    // ---- chain inputs of this band's rows (the chains' phase-1 rows 0..3 are ordinary inputs here)
+    {
+        float rv[6];
+        edge_rowvals(w, 64 * band + w.lane, true, rv);
+#pragma unroll
+        for (int k = 0; k < 6; k++) edge_all[k * LL_EDGE_PITCH + 64 * band + w.lane] = rv[k];
+        if (band == 7 && w.lane < 8) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) edge_all[k * LL_EDGE_PITCH + 512 + w.lane] = 0.f;
+        }
+    }
+    // ---- the 7 luma rows above the band's first build step: rows 64 b - 3 .. 64 b + 3 (band 0: rows -3..-1 are outside: zero)
+    {
+        uint32_t order = 0;
+#pragma unroll 1
+        for (int it = 0; it < 7; it++) {
+            const int row = 64 * band - 3 + it;  // state row `it`; every lane takes one 8-px chunk
+            uint4 bits = make_uint4(0, 0, 0, 0);
+            if (row >= 0) bits = row_bits(pack_row(load_px8(w.img + (size_t)row * row_stride + (size_t)(8 * w.lane) * 3), false, order));
+            *reinterpret_cast<uint4 *>(w.lds + G::OFF_STATE + it * 1024 + (8 * w.lane) * 2) = bits;
+        }
+    }
+    __syncthreads();
+    // ---- edge chains: lanes 0..5 of every wave run the recurrence from row 0 to the end of their own band
+    if (w.lane < 6) {
+        const float *in = edge_all + w.lane * LL_EDGE_PITCH;
+        float *mine = reinterpret_cast<float *>(w.lds + G::OFF_EDGE) + w.lane * 64;
+        float ecs = 0.f, ering[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) ering[t] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {  // phase 1 of the column box: rows 0..3 accumulate, no output
+            ecs = ecs + in[t];
+            ering[t] = in[t];
+        }
+#pragma unroll 1
+        for (int bb = 0; bb < band; bb++)  // bands above: only the state advances (row y = 64 bb + 4 + 8 u + e, ring slot y & 7)
+#pragma unroll 1
+            for (int u = 0; u < 8; u++) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = in[64 * bb + 4 + 8 * u + e];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    ecs = ecs + v[e];
+                    ecs = ecs - ering[(e + 4) & 7];
+                    ering[(e + 4) & 7] = v[e];
+                }
+            }
+#pragma unroll 1
+        for (int u = 0; u < 8; u++) {  // own band: outputs for rows 64 band + 8 u + e (edge_band with the band index a run-time value)
+            float v[8], out[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = in[64 * band + 4 + 8 * u + e];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const bool past_end = band == 7 && u == 7 && e >= 4;  // y >= 512: phase 4, nothing enters
+                if (!past_end) ecs = ecs + v[e];
+                ecs = ecs - ering[(e + 4) & 7];
+                ering[(e + 4) & 7] = v[e];
+                float o = ecs * 0.125f;
+                if (band == 0 && u == 0 && e < 3) o = ecs / (float)(5 + e);   // o = 0,1,2: windows 5,6,7
+                if (past_end) o = ecs / (float)(11 - e);                       // o = 508..511: windows 7,6,5,4
+                out[e] = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) mine[8 * u + e] = out[e];
+        }
+    }
+    wave_lds_fence();
+
+    // ---- the band itself
+    float *band_samples = samples + (size_t)band * (65 * 64);
+    if (band == 0)
+        ll_band<G, 0>(w, 0, band_samples);
+    else if (band == 7)
+        ll_band<G, 2>(w, 7, band_samples);
+    else
+        ll_band<G, 1>(w, band, band_samples);
+    __syncthreads();  // every wave's samples are written (the barrier waits for their stores) before wave 0 reads them
+    if (band != 0) return;
+
+    // ---- pass-2 column chain over all 512 rows (lane j = sampled column j reads slot j + 1) and the streaming tail
+    w.csum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w.cring[i] = 0.f;
+    rph::tail_init(w.tail);
+    const float *col = samples + (size_t)(w.lane + 1) * 64;
+#pragma unroll 1
+    for (int bb = 0; bb < 8; bb++) {
+        const float *cb = col + (size_t)bb * (65 * 64);
+#pragma unroll 1
+        for (int u = 0; u < 8; u++) {
+            const float4 lo = *reinterpret_cast<const float4 *>(cb + 8 * u), hi = *reinterpret_cast<const float4 *>(cb + 8 * u + 4);
+            const float in[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            float bnew = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {  // input row y = 64 bb + 8 u + e; (y & 7) == e
+                w.csum = w.csum + in[e];
+                w.csum = w.csum - w.cring[e];
+                w.cring[e] = in[e];
+                // y = 8 i + 8 entered: output row o = y - 4 = 8 i + 4, i = 8 bb + u - 1; /8 for the window, /64 for the scale
+                if (e == 0) bnew = w.csum * (0.125f * 0.015625f);
+            }
+            if (bb != 0 || u != 0) rph::tail_row(w.tail, bnew, 8 * bb + u - 1, w.lane, w.want_quality);
+        }
+    }
+    w.csum = w.csum - w.cring[0];
+    rph::tail_row(w.tail, (w.csum / 7.0f) * 0.015625f, 63, w.lane, w.want_quality);
+    wave_lds_fence();
+    rph::tail_finish(w.tail, reinterpret_cast<float *>(w.lds), w.lane, hash + (size_t)img * 32, quality ? quality + img : nullptr,
+                     coeffs ? coeffs + (size_t)img * 256 : nullptr, dihedral ? dihedral + (size_t)img * 256 : nullptr);
+    if (valid && w.lane == 0) valid[img] = 1;
+}
+
 }  // namespace
+
+// Low-latency launch: the sample scratch is the context's shared scratch (the generic kernel's planes), handed between streams with
+// the same event; called with ctx->mu held.
+int rph_launch_pdq_fused512_ll(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, size_t row_stride, size_t image_stride, uint8_t *d_hash,
+                               float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream)
+{
+    if (n == 0) return RPH_OK;
+    const uint32_t chunk = n < 1024 ? n : 1024;
+    const size_t need = (size_t)chunk * LL_SAMPLE_FLOATS * sizeof(float);
+    if (ctx->scratch_bytes < need) {
+        RPH_HIP_CHECK(hipDeviceSynchronize());  // kernels of any stream may still be using the old scratch
+        if (ctx->scratch) RPH_HIP_CHECK(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        RPH_HIP_CHECK(hipMalloc((void **)&ctx->scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    if (!ctx->scratch_done) RPH_HIP_CHECK(hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));
+    if (ctx->scratch_used && ctx->scratch_stream != stream) RPH_HIP_CHECK(hipStreamWaitEvent(stream, ctx->scratch_done, 0));
+    for (uint32_t first = 0; first < n; first += chunk) {
+        const uint32_t m = (n - first) < chunk ? (n - first) : chunk;
+        hipLaunchKernelGGL(pdq_fused512_ll_kernel<Geo<64>>, dim3(m), dim3(512), 0, stream, d_px + (size_t)first * image_stride, m, row_stride, image_stride,
+                           ctx->scratch, d_hash + (size_t)first * 32, d_quality ? d_quality + first : nullptr, d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr,
+                           d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr, d_valid ? d_valid + first : nullptr);
+        RPH_HIP_CHECK(hipGetLastError());
+    }
+    RPH_HIP_CHECK(hipEventRecord(ctx->scratch_done, stream));
+    ctx->scratch_stream = stream;
+    ctx->scratch_used = true;
+    return RPH_OK;
+}
 
 int rph_launch_pdq_fused512(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, size_t row_stride, size_t image_stride,
                             uint8_t *d_hash, float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid,
                             hipStream_t stream)
 {
     if (n == 0) return RPH_OK;
+    // 3 = the low-latency kernel, 4 (default) = automatic: below ~3 images per CU the eight-waves-per-image kernel finishes sooner
+    // (~60 us against ~300 us), above it the one-wave-per-image kernel has the throughput
+    if (ctx->pdq_kernel == 3 || (ctx->pdq_kernel == 4 && n < 768))
+        return rph_launch_pdq_fused512_ll(ctx, d_px, n, row_stride, image_stride, d_hash, d_quality, d_coeffs, d_dihedral, d_valid, stream);
     if (ctx->pdq_kernel == 2)
         hipLaunchKernelGGL(pdq_fused512_kernel<Geo<128>>, dim3(n), dim3(64), 0, stream, d_px, n, row_stride, image_stride, d_hash,
                            d_quality, d_coeffs, d_dihedral, d_valid);

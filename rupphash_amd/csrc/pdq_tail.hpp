@@ -33,6 +33,11 @@ __constant__ DctT c_dct_t = make_dct_t();
 
 constexpr int TAIL_LDS_FLOATS = 16 * 65 + 256;  // T[16][65] + C[256]
 
+// The tail is always run by ONE wave on LDS scratch private to it.  The LDS executes a wave's DS instructions in issue order, so
+// between a write and a read of another lane's value only the compiler has to keep the program order; a workgroup barrier here
+// would be wrong wherever the wave is part of a larger workgroup whose other waves do not run the tail (the low-latency PDQ kernel).
+__device__ __forceinline__ void tail_fence() { asm volatile("" ::: "memory"); }
+
 __device__ __forceinline__ uint32_t total_key(float f)
 {
     // f32::total_cmp as an unsigned ascending key
@@ -99,10 +104,10 @@ __device__ __forceinline__ void hashes_from_coeffs(const float (&c)[4], float *l
 
     const int cc = lane & 15;  // column of this lane's positions; row = (lane>>4) + 4m
     // transposed values: position (r, c) takes C[c][r]
-    __syncthreads();
+    tail_fence();
 #pragma unroll
     for (int m = 0; m < 4; m++) lds_c[lane + 64 * m] = c[m];
-    __syncthreads();
+    tail_fence();
     float t[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) t[m] = lds_c[16 * cc + ((lane >> 4) + 4 * m)];
@@ -186,10 +191,10 @@ __device__ __forceinline__ void tail_finish(TailAcc &a, float *lds, int lane, ui
     }
     float *lds_t = lds;            // [16][65]
     float *lds_c = lds + 16 * 65;  // [256]
-    __syncthreads();
+    tail_fence();
 #pragma unroll
     for (int i = 0; i < 16; i++) lds_t[i * 65 + lane] = a.t[i];
-    __syncthreads();
+    tail_fence();
 
     // ---- DCT pass 2: C[i][j] = sum_k T[i][k] * D[j][k]; this lane: j = lane & 15, i = (lane >> 4) + 4m
     float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};

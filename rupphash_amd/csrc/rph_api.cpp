@@ -309,7 +309,7 @@ int rph_hamming_set_kernel(rph_ctx *ctx, int which)
 
 int rph_pdq_set_kernel(rph_ctx *ctx, int which)
 {
-    if (!ctx || which < 0 || which > 2) return RPH_ERR_INVALID_ARG;
+    if (!ctx || which < 0 || which > 4) return RPH_ERR_INVALID_ARG;
     ctx->pdq_kernel = which;
     return RPH_OK;
 }

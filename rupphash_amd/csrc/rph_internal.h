@@ -40,7 +40,9 @@ struct rph_ctx {
     // 2 = fp4 MFMA formulation of the sweep's fast path, popcount-sorted {0,1} operands for plain all-pairs sweeps (default),
     // 3 = fp4 MFMA with +-1 operands everywhere, 4 = sorted {0,1} at every size, 1 = int8 MFMA, 0 = VALU xor + popcount
     int hamming_kernel = 2;
-    int pdq_kernel = 1;  // 0 = always generic; 1 / 2 = fused 512x512x3 kernel (64- / 128-px strips) where it applies
+    // 512x512 RGB8: 0 = always generic; 1 / 2 = fused one-wave-per-image kernel (64- / 128-px strips); 3 = fused low-latency kernel (eight
+    // waves per image); 4 = automatic: low-latency below 768 images per call, one-wave-per-image (64-px strips) from there
+    int pdq_kernel = 4;
 };
 
 void rph_set_error(const char *fmt, ...);

@@ -71,7 +71,7 @@ def test_pdq_generic_kernel_matches_oracle(eng, oracle, w, h, ch):
         imgs[0, ..., 0] = (np.arange(w)[None, :] * 255 // max(w - 1, 1)).astype(np.uint8)
     eng.set_pdq_kernel(0)
     out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
-    eng.set_pdq_kernel(1)
+    eng.set_pdq_kernel(4)
     for k in range(n):
         rc, coeffs, q = oracle.pdq_features(imgs[k])
         assert rc == 0 and out["valid"][k] == 1
@@ -94,7 +94,7 @@ def test_pdq_special_images(eng, oracle):
     imgs = np.stack([flat, black, white, checker, dot])
     eng.set_pdq_kernel(0)
     out = eng.pdq_hash_batch(imgs, want_coeffs=True, want_dihedral=True)
-    eng.set_pdq_kernel(1)
+    eng.set_pdq_kernel(4)
     for k in range(len(imgs)):
         rc, coeffs, q = oracle.pdq_features(imgs[k])
         assert np.array_equal(bits(out["coeffs"][k]), bits(coeffs)), k
@@ -189,7 +189,7 @@ def test_dihedral_hashes_match_physically_transformed_image(eng, oracle):
     eng.set_pdq_kernel(0)
     base = eng.pdq_hash_batch(img[None], want_dihedral=True)["dihedral"][0]
     got = eng.pdq_hash_batch(np.stack([np.ascontiguousarray(tr[v]) for v in range(8)]))["hash"]
-    eng.set_pdq_kernel(1)
+    eng.set_pdq_kernel(4)
     for v in range(8):
         assert np.array_equal(got[v], base[v]), v
 
@@ -466,12 +466,12 @@ def _fused_images():
     return np.stack(imgs)
 
 
-@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("which", [1, 2, 3])  # one wave per image (64- / 128-px strips), eight waves per image
 def test_fused512_kernel_matches_oracle_bit_for_bit(eng, oracle, which):
     imgs = _fused_images()
     eng.set_pdq_kernel(which)
     out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
-    eng.set_pdq_kernel(1)
+    eng.set_pdq_kernel(4)
     for k in range(len(imgs)):
         rc, coeffs, q = oracle.pdq_features(imgs[k])
         assert rc == 0 and out["valid"][k] == 1
@@ -481,13 +481,13 @@ def test_fused512_kernel_matches_oracle_bit_for_bit(eng, oracle, which):
         assert np.array_equal(out["dihedral"][k], oracle.dihedral_hashes(coeffs)), k
 
 
-@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("which", [1, 2, 3])
 def test_fused512_on_synthetic_bench_images(eng, oracle, which):
     """the bench workload itself: 24 images of the synthetic sequence (incl. a near-duplicate pair) vs the oracle"""
     imgs = eng.synth_images(990, 24)
     eng.set_pdq_kernel(which)
     out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True)
-    eng.set_pdq_kernel(1)
+    eng.set_pdq_kernel(4)
     ref_hash, ref_q, ref_c = oracle.pdq_batch_rgb(imgs, want_coeffs=True)
     assert np.array_equal(out["hash"], ref_hash)
     assert np.array_equal(bits(out["coeffs"]), bits(ref_c)) and np.array_equal(bits(out["quality"]), bits(ref_q))
@@ -503,7 +503,7 @@ def test_fused512_equals_generic_on_4096_images(eng):
     res = []
     try:
         eng.synth_images_dev(d_img, 123_000, n)
-        for which in (1, 2, 0):
+        for which in (1, 2, 3, 0):  # 3: the low-latency kernel in chunks of 1024 images
             eng.set_pdq_kernel(which)
             for p, nb in zip(bufs, (n * 32, n * 4, n * 1024)):
                 eng.dev_memset(p, 0xEE, nb)
@@ -513,10 +513,10 @@ def test_fused512_equals_generic_on_4096_images(eng):
             eng.dev_download(h, bufs[0]); eng.dev_download(q, bufs[1]); eng.dev_download(c, bufs[2])
             res.append((h, q, c))
     finally:
-        eng.set_pdq_kernel(1)
+        eng.set_pdq_kernel(4)
         for p in [d_img] + bufs:
             eng.dev_free(p)
-    for other in (1, 2):
+    for other in (1, 2, 3):
         assert np.array_equal(res[0][0], res[other][0])
         assert np.array_equal(bits(res[0][1]), bits(res[other][1])) and np.array_equal(bits(res[0][2]), bits(res[other][2]))
     # every 1000-image stripe holds one known near-duplicate pair (k % 1000 == 999 shares blocks with k - 1)
@@ -687,7 +687,7 @@ def test_pdq_strided_inputs_match_oracle(eng, oracle, w, h, ch, row_pad, img_pad
             eng.dev_free(d_px)
             eng.dev_free(d_h)
     finally:
-        eng.set_pdq_kernel(1)
+        eng.set_pdq_kernel(4)
     assert np.array_equal(dev_hashes, hashes)
     for k in range(n):
         rc, c, q = oracle.pdq_features(imgs[k])
