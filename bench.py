@@ -71,7 +71,8 @@ def parse_args():
     ap.add_argument("--hashes", type=int, default=1_000_000, help="hashes at N=1 (scaled by sqrt(N))")
     ap.add_argument("--threshold", type=int, default=32)
     ap.add_argument("--hamming-steps", type=int, default=0, help="default: same as --steps")
-    ap.add_argument("--pdq-kernel", type=int, default=1, help="1 = fused, 64-px strips (default), 2 = fused, 128-px strips, 0 = generic multi-pass")
+    ap.add_argument("--pdq-kernel", type=int, default=1, help="1 = fused, one wave per image, 64-px strips (default), 2 = the same with 128-px strips, "
+                    "3 = fused low-latency form (eight waves per image), 0 = generic multi-pass")
     ap.add_argument("--hamming-kernel", type=int, default=2, help="2 = fp4 MFMA fast path (default: popcount-sorted {0,1} operands), 3 = fp4 MFMA with +-1 operands, "
                     "1 = int8 MFMA fast path, 0 = VALU xor + popcount")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal: ranks may "
@@ -231,7 +232,7 @@ def main():
         if os.path.exists(tfile):
             with open(tfile) as f:
                 tj = json.load(f)
-            per_image = tj.get({0: "generic", 1: "fused512_strip64", 2: "fused512_strip128"}[args.pdq_kernel])
+            per_image = tj.get({0: "generic", 1: "fused512_strip64", 2: "fused512_strip128", 3: "fused512_low_latency"}[args.pdq_kernel])
             if per_image:
                 traffic_bytes = per_image * n_img
                 traffic_source = tj.get("source")
@@ -240,7 +241,8 @@ def main():
             "config": {"workload": f"batch PDQ hash of {n_img} synthetic 512x512 RGB8 images per GPU, resident in HBM "
                                    "(BASELINE config 2), hash-only output",
                        "images_per_gpu": n_img, "image": "512x512x3 u8",
-                       "pdq_kernel": {0: "generic", 1: "fused512/strip64", 2: "fused512/strip128"}[args.pdq_kernel], "hash_checksum": hash_checksum},
+                       "pdq_kernel": {0: "generic", 1: "fused512/strip64", 2: "fused512/strip128", 3: "fused512/low-latency"}[args.pdq_kernel],
+                       "hash_checksum": hash_checksum},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic_bytes, "traffic_source": traffic_source,
                          "traffic_counts": "L2->fabric read bytes (Infinity-Cache hits included)",
