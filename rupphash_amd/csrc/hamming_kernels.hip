@@ -112,12 +112,20 @@ __device__ __forceinline__ void seg_block(unsigned long long b, uint32_t nt, uin
 __device__ __forceinline__ void complete_pair(const SweepArgs &a, const uint32_t *__restrict__ rowp, const uint32_t *colp,
                                               unsigned long long owner, unsigned long long col, uint32_t variant)
 {
+    // first half of the two hashes: its distance is a lower bound, and most pairs a candidate drags in (the rest of its lane's
+    // column blocks and rows) fail here, at half the bytes
     uint32_t x[8];
     uint32_t d = 0;
+    {
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(rowp), c0 = *reinterpret_cast<const uint4 *>(colp);
+        x[0] = r0.x ^ c0.x; x[1] = r0.y ^ c0.y; x[2] = r0.z ^ c0.z; x[3] = r0.w ^ c0.w;
 #pragma unroll
-    for (int w = 0; w < 8; w++) {
-        x[w] = rowp[w] ^ colp[w];
-        d += (uint32_t)__builtin_popcount(x[w]);
+        for (int w = 0; w < 4; w++) d += (uint32_t)__builtin_popcount(x[w]);
+        if (d > a.threshold) return;
+        const uint4 r1 = *reinterpret_cast<const uint4 *>(rowp + 4), c1 = *reinterpret_cast<const uint4 *>(colp + 4);
+        x[4] = r1.x ^ c1.x; x[5] = r1.y ^ c1.y; x[6] = r1.z ^ c1.z; x[7] = r1.w ^ c1.w;
+#pragma unroll
+        for (int w = 4; w < 8; w++) d += (uint32_t)__builtin_popcount(x[w]);
     }
     if (variant > 0 && a.has_features && !a.has_features[owner]) return;
     if (col >= a.n) return;
