@@ -108,20 +108,28 @@ __device__ __forceinline__ void seg_block(unsigned long long b, uint32_t nt, uin
 }
 
 // Slow path for one (row, column) pair whose partial distance passed: exact distance,
-// owner / limit rules, find_groups reachability flags, append.
-__device__ __forceinline__ void complete_pair(const SweepArgs &a, const uint32_t *__restrict__ rowp, const uint32_t *colp,
-                                              unsigned long long owner, unsigned long long col, uint32_t variant)
+// owner / limit rules, find_groups reachability flags, append.  In two steps so that a drain can issue the first-half loads of
+// several pairs before it looks at any of them.
+// Step 1: first half of the two hashes.  Its distance is a lower bound, and most pairs a candidate drags in (the rest of its lane's
+// column blocks and rows) fail here, at half the bytes.
+__device__ __forceinline__ uint32_t first_half_distance(const uint32_t *__restrict__ rowp, const uint32_t *colp, uint32_t x[4])
 {
-    // first half of the two hashes: its distance is a lower bound, and most pairs a candidate drags in (the rest of its lane's
-    // column blocks and rows) fail here, at half the bytes
-    uint32_t x[8];
+    const uint4 r0 = *reinterpret_cast<const uint4 *>(rowp), c0 = *reinterpret_cast<const uint4 *>(colp);
+    x[0] = r0.x ^ c0.x; x[1] = r0.y ^ c0.y; x[2] = r0.z ^ c0.z; x[3] = r0.w ^ c0.w;
     uint32_t d = 0;
-    {
-        const uint4 r0 = *reinterpret_cast<const uint4 *>(rowp), c0 = *reinterpret_cast<const uint4 *>(colp);
-        x[0] = r0.x ^ c0.x; x[1] = r0.y ^ c0.y; x[2] = r0.z ^ c0.z; x[3] = r0.w ^ c0.w;
 #pragma unroll
-        for (int w = 0; w < 4; w++) d += (uint32_t)__builtin_popcount(x[w]);
-        if (d > a.threshold) return;
+    for (int w = 0; w < 4; w++) d += (uint32_t)__builtin_popcount(x[w]);
+    return d;
+}
+
+// Step 2, for a pair whose first-half distance d (differences x0) is within the threshold.
+__device__ __forceinline__ void complete_rest(const SweepArgs &a, const uint32_t *__restrict__ rowp, const uint32_t *colp, const uint32_t x0[4],
+                                              uint32_t d, unsigned long long owner, unsigned long long col, uint32_t variant)
+{
+    uint32_t x[8];
+    {
+#pragma unroll
+        for (int w = 0; w < 4; w++) x[w] = x0[w];
         const uint4 r1 = *reinterpret_cast<const uint4 *>(rowp + 4), c1 = *reinterpret_cast<const uint4 *>(colp + 4);
         x[4] = r1.x ^ c1.x; x[5] = r1.y ^ c1.y; x[6] = r1.z ^ c1.z; x[7] = r1.w ^ c1.w;
 #pragma unroll
@@ -159,6 +167,14 @@ __device__ __forceinline__ void complete_pair(const SweepArgs &a, const uint32_t
         e.flags = (uint16_t)flags;
         a.edges[at] = e;
     }
+}
+
+__device__ __forceinline__ void complete_pair(const SweepArgs &a, const uint32_t *__restrict__ rowp, const uint32_t *colp,
+                                              unsigned long long owner, unsigned long long col, uint32_t variant)
+{
+    uint32_t x[4];
+    const uint32_t d = first_half_distance(rowp, colp, x);
+    if (d <= a.threshold) complete_rest(a, rowp, colp, x, d, owner, col, variant);
 }
 
 template <int PW>
@@ -243,6 +259,9 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int MF_BLOCK = 256;   // 4 waves; wave w owns rows 256 w .. 256 w + 255 of the 1024-row tile
+#ifndef RPH_SWEEP_NCG
+#define RPH_SWEEP_NCG 4
+#endif
 
 // byte v -> 8 bytes, byte i = bit i of v ? +1 : -1
 __device__ __forceinline__ uint2 expand_byte(uint32_t v)
@@ -409,7 +428,9 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
     constexpr int PASS_ROWS = 4 * 32 * MF_RB;     // rows one pass of the 4 waves covers; T_FILES / PASS_ROWS passes per tile
     static_assert(!U64 || PW == 2, "u64 hashes are swept at full width");
     constexpr int NCB = CHUNK / 32;               // 32-column blocks per chunk
-    constexpr int NRP = MF_RB / 2;                // row-block pairs per wave and pass (one screen result each per chunk)
+    constexpr int NRP = MF_RB / 2;                // row-block pairs per wave and pass
+    constexpr int NCG = RPH_SWEEP_NCG < NCB ? RPH_SWEEP_NCG : NCB;  // column-block groups per chunk (cb % NCG): one running maximum per (row-block pair, group)
+    static_assert(NCB % NCG == 0 && NRP * NCG <= 32, "candidate bitmap of a chunk is one dword");
     typedef typename F::Acc Acc;
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2 * CHUNK * PITCH];
     __shared__ typename F::Lut s_lut[256];
@@ -431,7 +452,7 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
     if (threadIdx.x < 4) s_qn[threadIdx.x] = 0;
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform and known to be: scalar addresses, scalar loads
     const int c32 = lane & 31, h = lane >> 5;
     constexpr bool ZO = is_zero_one<F>::value;
     const int thresh_key = F::thresh_key(32 * PW - 2 * (int)a.threshold);  // +-1 encoding: partial distance <= threshold  <=>  dot >= 32 PW - 2 threshold
@@ -513,12 +534,17 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
             // chunk: 16 three-input maxima per pair of tiles and nothing else (the compare, select and or of a per-tile test cost
             // another 4 VALU instructions per 4 MFMAs, and the SIMD's issue port is what this loop is short of).  A candidate is
             // then known up to its column block; the (rare) completion examines the lane's column in every block of the chunk.
-            int runmax[NRP];
+            int runmax[NCG][NRP];
 #pragma unroll
-            for (int p = 0; p < NRP; p++) runmax[p] = (int)0x80000000;
+            for (int g = 0; g < NCG; g++)
+#pragma unroll
+                for (int p = 0; p < NRP; p++) runmax[g][p] = (int)0x80000000;
 #pragma unroll 1
-            for (int cb = 0; cb < NCB; cb++) {
-                if (cbase + cb * 32 >= ncols) break;
+            for (int cb0 = 0; cb0 < NCB; cb0 += NCG) {
+                if (cbase + cb0 * 32 >= ncols) break;
+#pragma unroll
+              for (int g = 0; g < NCG; g++) {
+                const int cb = cb0 + g;  // (columns past the end of the segment were expanded as zeros: dot 0)
                 v4i B[NF];
                 const uint8_t *bp = s_b + (cb * 32 + c32) * PITCH + h * NF * 16;
 #pragma unroll
@@ -546,21 +572,25 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
                         acc0 = F::mfma(A[rb][f], B[f], acc0);
                         acc1 = F::mfma(A[rb + 1][f], B[f], acc1);
                     }
-                    runmax[rb / 2] = max33(acc0, acc1, runmax[rb / 2]);
+                    runmax[g][rb / 2] = max33(acc0, acc1, runmax[g][rb / 2]);
                 }
+              }
             }
-            uint32_t cand = 0;  // bit p: this lane saw a candidate among its pairs of row blocks 2p, 2p + 1 in some column block of the chunk
+            uint32_t cand = 0;  // bit g * NRP + p: this lane saw a candidate among its pairs of row blocks 2p, 2p + 1 in a column block cb = g (mod NCG) of the chunk
             if (ZO) {
                 // {0,1} encoding on popcount-sorted hashes: dot >= ceil((pa + pb - threshold) / 2) with the smallest pa of the 64 rows and
                 // the smallest pb of the chunk's columns
 #pragma unroll
                 for (int p = 0; p < NRP; p++) {
-                    const int need = (pa_min[p] + pb_min - (int)a.threshold + 1) >> 1;  // arithmetic shift = floor: ceil(x / 2) for any sign
-                    cand |= (runmax[p] >= F::thresh_key(need)) ? (1u << p) : 0u;
+                    const int need = F::thresh_key((pa_min[p] + pb_min - (int)a.threshold + 1) >> 1);  // arithmetic shift = floor: ceil(x / 2) for any sign
+#pragma unroll
+                    for (int g = 0; g < NCG; g++) cand |= (runmax[g][p] >= need) ? (1u << (g * NRP + p)) : 0u;
                 }
             } else {
 #pragma unroll
-                for (int p = 0; p < NRP; p++) cand |= (runmax[p] >= thresh_key) ? (1u << p) : 0u;
+                for (int g = 0; g < NCG; g++)
+#pragma unroll
+                    for (int p = 0; p < NRP; p++) cand |= (runmax[g][p] >= thresh_key) ? (1u << (g * NRP + p)) : 0u;
             }
 
             // ---- lanes with candidates append (bitmap, column) to the wave's queue: slots by ballot rank, no atomics
@@ -584,22 +614,61 @@ __global__ void __launch_bounds__(MF_BLOCK, F::blocks_per_cu(PW)) hamming_mfma_k
                 undrained = cend;
             } else if (nq >= 64 || cend == ncols) {
                 if (nq <= QCAP) {
-                    // entries one after the other (wave-uniform), the lanes share the pairs of an entry: for every set bit the queued
-                    // lane's column in each of the NCB column blocks of its chunk against its 32 rows (C/D layout of the two tiles:
-                    // row = (r & 3) + 8 (r >> 2) + 4 h).  NCB * 32 items, two per lane and round so that their loads overlap.
-                    for (uint32_t t = 0; t < nq; t++) {
-                        const uint2 e = s_q[wave][t];  // same address in every lane: a broadcast read
-                        const uint32_t eh = e.y >> 16;
-                        uint32_t bm = e.x;
-                        while (bm != 0) {
-                            const uint32_t rb = 2u * (uint32_t)__builtin_ctz(bm);
-                            bm &= bm - 1;
+                    // Each half-wave takes U entries per round; its 32 lanes share the pairs of an entry: for a set bit, the queued
+                    // lane's column in the NCB / NCG column blocks of the bit's group against its 32 rows (C/D layout of the two tiles:
+                    // row = (r & 3) + 8 (r >> 2) + 4 h).  The first-half loads of a round (2 U entries, first set bit each) are issued
+                    // together and looked at afterwards: a drain is a chain of global-memory round trips, and this is what shortens it.
+                    // Further set bits of an entry (rare: two candidates of one lane in one chunk) follow one by one.
+                    constexpr int U = 2, IPB = NCB / NCG;
+                    auto item_of = [&](const uint2 e, uint32_t bit, uint32_t k, unsigned long long &owner, unsigned long long &col) -> bool {
+                        const uint32_t r = lane & 31u, eh = e.y >> 16, rb = 2u * (bit % NRP), cb = k * NCG + bit / NRP;
+                        const uint32_t cidx = (e.y & 0xFFFFu) + 32u * cb;
+                        col = col0 + cidx;
+                        owner = row0 + wrow + 32u * (rb + (r >> 4)) + (r & 3u) + 8u * ((r >> 2) & 3u) + 4u * eh;
+                        return owner < a.n && cidx < ncols;
+                    };
+                    for (uint32_t t0 = 0; t0 < nq; t0 += 2 * U) {
+                        uint2 e[U];
 #pragma unroll
-                            for (uint32_t item = lane; item < (uint32_t)NCB * 32u; item += 64) {
-                                const uint32_t r = item & 31u, cb = item >> 5;
-                                const unsigned long long col = col0 + (e.y & 0xFFFFu) + 32u * cb;
-                                const unsigned long long owner = row0 + wrow + 32u * (rb + (r >> 4)) + (r & 3u) + 8u * ((r >> 2) & 3u) + 4u * eh;
-                                if (owner < a.n && (e.y & 0xFFFFu) + 32u * cb < ncols) complete(owner, col);
+                        for (int u = 0; u < U; u++) {
+                            const uint32_t t = t0 + 2u * u + (uint32_t)(lane >> 5);
+                            e[u] = s_q[wave][t < nq ? t : 0u];  // same address within a half-wave: a broadcast read
+                            if (t >= nq) e[u].x = 0;
+                        }
+                        if (!U64) {
+                            uint32_t x[U][IPB][4], d[U][IPB];
+#pragma unroll
+                            for (int u = 0; u < U; u++)
+#pragma unroll
+                                for (int k = 0; k < IPB; k++) {
+                                    unsigned long long owner, col;
+                                    const bool ok = item_of(e[u], e[u].x ? (uint32_t)__builtin_ctz(e[u].x) : 0u, k, owner, col) && e[u].x != 0;
+                                    const uint32_t dd = first_half_distance(a.rows + ((ok ? owner : 0ull) * nv + v) * 8, a.cols + (ok ? col : 0ull) * 8, x[u][k]);
+                                    d[u][k] = ok ? dd : 0xFFFFFFFFu;
+                                }
+#pragma unroll
+                            for (int u = 0; u < U; u++)
+#pragma unroll
+                                for (int k = 0; k < IPB; k++)
+                                    if (d[u][k] <= a.threshold) {
+                                        unsigned long long owner, col;
+                                        item_of(e[u], (uint32_t)__builtin_ctz(e[u].x), k, owner, col);
+                                        complete_rest(a, a.rows + (owner * nv + v) * 8, a.cols + col * 8, x[u][k], d[u][k], owner, col, v);
+                                    }
+#pragma unroll
+                            for (int u = 0; u < U; u++) e[u].x &= e[u].x - 1;  // (0 stays 0)
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            uint32_t bm = e[u].x;
+                            while (bm != 0) {
+                                const uint32_t bit = (uint32_t)__builtin_ctz(bm);
+                                bm &= bm - 1;
+#pragma unroll
+                                for (int k = 0; k < IPB; k++) {
+                                    unsigned long long owner, col;
+                                    if (item_of(e[u], bit, k, owner, col)) complete(owner, col);
+                                }
                             }
                         }
                     }
@@ -697,12 +766,15 @@ __global__ void __launch_bounds__(256) hamming64_sweep_kernel(Sweep64Args a)
 // The smallest PW that leaves >= 4.2 sigma to the threshold lets fewer than ~1.3e-5 of the pairs through (<= 7 M exact
 // completions per 5e11 pairs, well under a millisecond); correctness never depends on it (the completion is exact, and a
 // flooded candidate queue falls back to exhaustive completion).  kernel 2 (fp4) works on 64-bit slices: PW even.
+#ifndef RPH_FP4_SIGMA
+#define RPH_FP4_SIGMA 4.0
+#endif
 extern "C" int rph_hamming_prefix_dwords(uint32_t threshold, int kernel)
 {
     int pw = 8;
     for (int cand = 4; cand < 8; cand++) {
         const double mean = 16.0 * cand, sigma = sqrt(8.0 * cand);
-        if ((mean - (double)threshold) / sigma >= 4.2) {
+        if ((mean - (double)threshold) / sigma >= (kernel >= 2 ? RPH_FP4_SIGMA : 4.2)) {
             pw = cand;
             break;
         }

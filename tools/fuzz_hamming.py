@@ -35,6 +35,7 @@ while time.time() - t0 < budget:
         h[: min(n, int(rng.integers(64, 700)))] = h[0]
     nparts = int(rng.choice([1, 1, 2, 3, 5]))
     res = {}
+    t_case = time.time()
     if style == 2:  # skewed bit densities: the popcount-sorted {0,1} form thresholds on popcounts
         dens = rng.choice([0.03, 0.2, 0.5, 0.8, 0.97], n)
         h = np.packbits((rng.random((n, 256)) < dens[:, None]).astype(np.uint8), axis=1)
@@ -49,5 +50,7 @@ while time.time() - t0 < budget:
         res[kern] = key(np.concatenate(parts))
     assert all(res[0].shape == res[k].shape and (res[0] == res[k]).all() for k in (1, 3, 4)), (n, thr, style, nparts)
     cases += 1
+    if time.time() - t_case > 5.0:  # (edge-heavy cases spend their time in the host-side sort of the comparison)
+        print(f"  case {cases - 1}: n {n} thr {thr} style {int(style)} nparts {nparts}: {len(res[0])} edges, {time.time() - t_case:.1f} s", flush=True)
 eng.set_hamming_kernel(2)
 print(f"seed {seed}: {cases} random cases, all four sweep formulations agree edge for edge")
