@@ -5,22 +5,26 @@
 // One image per GPU call would spend its time in launch and PCIe latency, so concurrent callers are coalesced here, and the
 // transfers of consecutive batches are pipelined:
 //
-//   * three pipeline slots, each with its own HIP stream, pinned host staging and device buffers; at most two batches are in
-//     flight (H2D of one overlaps the kernels / D2H of the other) while the third slot fills;
+//   * five pipeline slots, each with its own HIP stream, pinned host staging and device buffers; at most three batches are in
+//     flight (the H2D of one overlaps the kernels / D2H of the others) while another slot fills and one is read out;
 //   * a caller joins the open batch and copies its pixels into the slot's pinned staging itself (outside the lock: the copies of
-//     different callers run in parallel on their own cores);
-//   * a batch goes as soon as nobody is still copying into it AND a pipeline slot is free -- no timer: under load the batch size
-//     adapts to the arrival rate (callers that arrive while two batches are in flight accumulate), an isolated caller is served at
+//     different callers run in parallel on their own cores).  The batch's pixels then cross PCIe in ONE transfer: a 0.8 MB copy
+//     costs 23-46 us (17-35 GB/s), 6 MB and more run at 52-57 GB/s (tools/h2d_rate.cpp), so per-caller transfers lose;
+//   * a batch goes as soon as nobody is still copying into it AND the pipeline has room -- no timer: under load the batch size
+//     adapts to the arrival rate (callers that arrive while the pipeline is full accumulate), an isolated caller is served at
 //     once.  `max_wait_us` (default 0) optionally holds a non-full batch back for more callers;
-//   * a batch takes at most half of the callers that were recently inside at once: blocking callers that all sit in ONE batch
-//     march in lockstep (copy, transfer, kernel, wake, copy, ...) and nothing overlaps; two half-size groups fall out of step after
-//     the first round and then one group copies while the other's pixels cross PCIe;
+//   * a batch takes at most a third (half, below six callers) of the callers that were recently inside at once: blocking callers
+//     that all sit in ONE batch march in lockstep (copy, transfer, kernel, wake, copy, ...) and nothing overlaps; smaller groups
+//     fall out of step after the first round and then one group copies while another's pixels cross PCIe and a third one's
+//     kernel runs (measured: three groups beat two by 10-17 % from 16 callers up and tie below; four are no better);
 //   * a batch may hold images of different geometry (a scan of mixed-size photos): they share the transfer and the
 //     synchronisation, and every run of consecutive images with one geometry is one rph_pdq_hash_batch_dev call on the slot's stream.
 // Whichever caller finds the batch ready becomes its leader, runs it and wakes the others.
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -30,11 +34,14 @@
 
 namespace {
 
-constexpr int kSlots = 3;                          // pipeline depth: two in flight + one filling
-constexpr uint32_t kMaxInflight = 2;
-constexpr size_t kSlotPixelBytes = (size_t)128 << 20;  // pinned staging per slot (one larger image still gets a slot of its own size)
+constexpr int kSlots = 5;                          // pipeline depth: up to three batches in flight + one filling + one being read out
+constexpr uint32_t kMaxInflight = 3;
+constexpr size_t kSlotPixelBytes = (size_t)64 << 20;  // pinned staging per slot (one larger image still gets a slot of its own size)
+static const bool kTrace = getenv("RPH_BATCHER_TRACE") != nullptr;  // per-batch phase times on stderr when the context goes
 constexpr uint32_t kSlotImages = 4096;             // result records per slot
 constexpr size_t kRecordBytes = 32 + 4 + 1 + 1024 + 16;  // hash, quality, valid, coefficients (+ alignment slack)
+
+double g_ev[4];  // trace: summed stage times on the GPU timeline (ms; updated by batch leaders, read at teardown)
 
 struct Slot {
     hipStream_t stream = nullptr;
@@ -93,7 +100,7 @@ struct Batch {
     bool running = false;  // a leader has taken it
     bool done = false;
     int status = RPH_OK;
-    std::chrono::steady_clock::time_point last_join;
+    std::chrono::steady_clock::time_point last_join, t_open, t_copied, t_done;
     std::condition_variable cv;  // its callers wait here: done (all), or a chance to lead it (one)
 };
 
@@ -109,8 +116,16 @@ struct Batcher {
     uint32_t max_batch = 256;
     uint32_t max_wait_us = 0;
     uint64_t n_batches = 0, n_images = 0;
+    double t_fill = 0, t_wait = 0, t_run = 0, t_read = 0;  // trace: open -> last copy done, -> leader starts, run_batch, done -> slot free
     ~Batcher()
     {
+        if (kTrace && n_batches)
+            fprintf(stderr, "batcher: %llu batches, %.1f images each; per batch: fill %.0f us, wait for pipeline %.0f us, run %.0f us, read out %.0f us\n",
+                    (unsigned long long)n_batches, (double)n_images / n_batches, 1e6 * t_fill / n_batches, 1e6 * t_wait / n_batches, 1e6 * t_run / n_batches,
+                    1e6 * t_read / n_batches);
+        if (kTrace && n_batches)
+            fprintf(stderr, "         on the GPU timeline per batch: H2D %.0f us, kernels %.0f us, D2H %.0f us\n", 1e3 * g_ev[0] / n_batches, 1e3 * g_ev[1] / n_batches,
+                    1e3 * g_ev[2] / n_batches);
         for (Slot &s : slots) s.release();
     }
 };
@@ -132,12 +147,18 @@ int run_batch(rph_ctx *ctx, Batch &b)
 {
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
     Slot &s = *b.slot;
+    hipEvent_t ev[4] = {};
+    if (kTrace) {
+        for (auto &e : ev) (void)hipEventCreate(&e);
+        (void)hipEventRecord(ev[0], s.stream);
+    }
     const uint32_t n = (uint32_t)b.items.size();
     b.o_q = (size_t)n * 32;
     b.o_v = b.o_q + (size_t)n * 4;
     b.o_c = align16(b.o_v + n);
     uint8_t *d_out = (uint8_t *)s.d_out;
     RPH_HIP_CHECK(hipMemcpyAsync(s.d_px, s.h_px, b.bytes, hipMemcpyHostToDevice, s.stream));
+    if (kTrace) (void)hipEventRecord(ev[1], s.stream);
     for (uint32_t first = 0; first < n;) {  // one launch sequence per run of equal geometry (packed back to back at a uniform stride)
         const Item &a = b.items[first];
         const size_t image_bytes = (size_t)a.w * a.h * a.channels, stride = align16(image_bytes);
@@ -154,8 +175,18 @@ int run_batch(rph_ctx *ctx, Batch &b)
         }
         first += m;
     }
+    if (kTrace) (void)hipEventRecord(ev[2], s.stream);
     RPH_HIP_CHECK(hipMemcpyAsync(s.h_out, s.d_out, b.want_coeffs ? b.o_c + (size_t)n * 1024 : b.o_v + n, hipMemcpyDeviceToHost, s.stream));
+    if (kTrace) (void)hipEventRecord(ev[3], s.stream);
     RPH_HIP_CHECK(hipStreamSynchronize(s.stream));
+    if (kTrace) {
+        float ms = 0;
+        for (int i = 0; i < 3; i++) {
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            g_ev[i] += ms;
+        }
+        for (auto &e : ev) (void)hipEventDestroy(e);
+    }
     return RPH_OK;
 }
 
@@ -244,7 +275,9 @@ extern "C" int rph_pdq_hash_one(rph_ctx *ctx, const uint8_t *px, uint32_t w, uin
                 free_slot->busy = true;
                 b = std::make_shared<Batch>();
                 b->slot = free_slot;
-                b->cap = std::min<uint32_t>(B.max_batch, std::max<uint32_t>(1, (uint32_t)((B.crowd + 1.0) / 2.0)));
+                const double groups = B.crowd >= 6.0 ? 3.0 : 2.0;
+                b->cap = std::min<uint32_t>(B.max_batch, std::max<uint32_t>(1, (uint32_t)((B.crowd + groups - 1.0) / groups)));
+                b->t_open = std::chrono::steady_clock::now();
                 b->items.reserve(b->cap);
                 B.open = b;
                 B.live.push_back(b);
@@ -272,6 +305,7 @@ extern "C" int rph_pdq_hash_one(rph_ctx *ctx, const uint8_t *px, uint32_t w, uin
         }
         lock.lock();
         b->copying--;
+        if (kTrace) b->t_copied = std::chrono::steady_clock::now();
         // ---- wait for the batch; whoever finds it ready to go runs it
         while (!b->done) {
             if (!b->running && b->copying == 0 && B.inflight < kMaxInflight) {
@@ -292,9 +326,16 @@ extern "C" int rph_pdq_hash_one(rph_ctx *ctx, const uint8_t *px, uint32_t w, uin
                     B.inflight++;
                     B.n_batches++;
                     B.n_images += b->items.size();
+                    const auto t_go = std::chrono::steady_clock::now();
                     lock.unlock();
                     const int rc = run_batch(ctx, *b);
                     lock.lock();
+                    if (kTrace) {
+                        b->t_done = std::chrono::steady_clock::now();
+                        B.t_fill += std::chrono::duration<double>(b->t_copied - b->t_open).count();
+                        B.t_wait += std::chrono::duration<double>(t_go - b->t_copied).count();
+                        B.t_run += std::chrono::duration<double>(b->t_done - t_go).count();
+                    }
                     b->status = rc;
                     b->done = true;
                     B.inflight--;
@@ -317,6 +358,7 @@ extern "C" int rph_pdq_hash_one(rph_ctx *ctx, const uint8_t *px, uint32_t w, uin
         }
         lock.lock();
         if (--b->readers == 0) {  // last caller out: the slot is free again
+            if (kTrace) B.t_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - b->t_done).count();
             b->slot->busy = false;
             B.live.erase(std::remove(B.live.begin(), B.live.end(), b), B.live.end());
             B.cv_slot.notify_all();

@@ -863,34 +863,37 @@ __global__ void __launch_bounds__(512, 2) pdq_fused512_ll_kernel(const uint8_t *
 
 }  // namespace
 
-// Low-latency launch: the sample scratch is the context's shared scratch (the generic kernel's planes), handed between streams with
-// the same event; called with ctx->mu held.
+// Low-latency launch: the sample scratch belongs to the caller's stream (ctx->ll_scratch), so launches on different streams run side
+// by side; called with ctx->mu held.
 int rph_launch_pdq_fused512_ll(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, size_t row_stride, size_t image_stride, uint8_t *d_hash,
                                float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream)
 {
     if (n == 0) return RPH_OK;
-    const uint32_t chunk = n < 1024 ? n : 1024;
+    const uint32_t chunk = n < 256 ? n : 256;  // one image per CU is all that runs at once
     const size_t need = (size_t)chunk * LL_SAMPLE_FLOATS * sizeof(float);
-    if (ctx->scratch_bytes < need) {
-        RPH_HIP_CHECK(hipDeviceSynchronize());  // kernels of any stream may still be using the old scratch
-        if (ctx->scratch) RPH_HIP_CHECK(hipFree(ctx->scratch));
-        ctx->scratch = nullptr;
-        ctx->scratch_bytes = 0;
-        RPH_HIP_CHECK(hipMalloc((void **)&ctx->scratch, need));
-        ctx->scratch_bytes = need;
+    if (ctx->ll_scratch.size() > 256 && ctx->ll_scratch.find(stream) == ctx->ll_scratch.end()) {  // streams come and go: start over
+        RPH_HIP_CHECK(hipDeviceSynchronize());
+        for (auto &kv : ctx->ll_scratch) (void)hipFree(kv.second.p);
+        ctx->ll_scratch.clear();
     }
-    if (!ctx->scratch_done) RPH_HIP_CHECK(hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));
-    if (ctx->scratch_used && ctx->scratch_stream != stream) RPH_HIP_CHECK(hipStreamWaitEvent(stream, ctx->scratch_done, 0));
+    rph_ctx::LLScratch &sc = ctx->ll_scratch[stream];
+    if (sc.bytes < need) {
+        if (sc.p) {
+            RPH_HIP_CHECK(hipStreamSynchronize(stream));  // only this stream's kernels use it
+            RPH_HIP_CHECK(hipFree(sc.p));
+        }
+        sc.p = nullptr;
+        sc.bytes = 0;
+        RPH_HIP_CHECK(hipMalloc((void **)&sc.p, need));
+        sc.bytes = need;
+    }
     for (uint32_t first = 0; first < n; first += chunk) {
         const uint32_t m = (n - first) < chunk ? (n - first) : chunk;
         hipLaunchKernelGGL(pdq_fused512_ll_kernel<Geo<64>>, dim3(m), dim3(512), 0, stream, d_px + (size_t)first * image_stride, m, row_stride, image_stride,
-                           ctx->scratch, d_hash + (size_t)first * 32, d_quality ? d_quality + first : nullptr, d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr,
+                           sc.p, d_hash + (size_t)first * 32, d_quality ? d_quality + first : nullptr, d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr,
                            d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr, d_valid ? d_valid + first : nullptr);
         RPH_HIP_CHECK(hipGetLastError());
     }
-    RPH_HIP_CHECK(hipEventRecord(ctx->scratch_done, stream));
-    ctx->scratch_stream = stream;
-    ctx->scratch_used = true;
     return RPH_OK;
 }
 

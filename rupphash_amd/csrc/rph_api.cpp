@@ -271,6 +271,7 @@ int rph_shutdown(rph_ctx *ctx)
     rph_pipe_forget(ctx);
     rph_resize_forget(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (auto &kv : ctx->ll_scratch) (void)hipFree(kv.second.p);
     if (ctx->sink) (void)hipFree(ctx->sink);
     if (ctx->scratch_done) (void)hipEventDestroy(ctx->scratch_done);
     if (ctx->sweep_scratch) (void)hipFree(ctx->sweep_scratch);
@@ -848,6 +849,11 @@ int rph_stream_destroy(rph_ctx *ctx, void *stream)
     RPH_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     if (ctx->scratch_stream == (hipStream_t)stream) ctx->scratch_used = false;  // its work is complete: nothing left to order behind
     if (ctx->sweep_stream == (hipStream_t)stream) ctx->sweep_used = false;
+    auto ll = ctx->ll_scratch.find((hipStream_t)stream);
+    if (ll != ctx->ll_scratch.end()) {
+        (void)hipFree(ll->second.p);
+        ctx->ll_scratch.erase(ll);
+    }
     RPH_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
     return RPH_OK;
 }

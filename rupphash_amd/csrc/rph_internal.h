@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <exception>
+#include <map>
 #include <mutex>
 #include <new>
 
@@ -21,6 +22,13 @@ struct rph_ctx {
     hipEvent_t scratch_done = nullptr;
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
+    // sample scratch of the low-latency PDQ kernel, one per caller stream (133 KB per image of a launch chunk): launches on different
+    // streams -- the one-image queue's pipeline slots -- share nothing and need no ordering between them
+    struct LLScratch {
+        float *p = nullptr;
+        size_t bytes = 0;
+    };
+    std::map<hipStream_t, LLScratch> ll_scratch;
     // rph_pdq_hash_batch (host pointers): two pinned staging sets + device twins, alternated over two streams so that the host
     // copy / H2D of one chunk overlaps the transfer and kernels of the other (rph_api.cpp); one host-batch call at a time
     std::mutex pipe_mu;

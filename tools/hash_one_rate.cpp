@@ -10,8 +10,12 @@
 
 #include "rupphash.h"
 
-int main()
+int main(int argc, char **argv)
 {
+    // optional arguments: thread counts (default 1 4 8 16 32 64); RPH_RATE_ONLY512=1 skips the resized geometry
+    std::vector<int> counts;
+    for (int i = 1; i < argc; i++) counts.push_back(std::atoi(argv[i]));
+    if (counts.empty()) counts = {1, 4, 8, 16, 32, 64};
     rph_ctx *ctx = nullptr;
     if (rph_init(0, &ctx) != RPH_OK) {
         std::printf("no device: %s\n", rph_last_error());
@@ -22,6 +26,7 @@ int main()
         uint32_t w, h;
     } geos[] = {{"512x512 RGB8", 512, 512}, {"1280x854 RGB8 (resized path)", 1280, 854}};
     for (const Geo &g : geos) {
+        if (g.w != 512 && std::getenv("RPH_RATE_ONLY512")) continue;
         const size_t bytes = (size_t)g.w * g.h * 3;
         std::vector<std::vector<uint8_t>> pool(32, std::vector<uint8_t>(bytes));
         uint32_t x = 12345;
@@ -30,7 +35,7 @@ int main()
                 x = x * 1664525u + 1013904223u;
                 b = (uint8_t)(x >> 24);
             }
-        for (int threads : {1, 4, 8, 16, 32, 64}) {
+        for (int threads : counts) {
             const int per = std::max(8, (g.w == 512 ? 16384 : 4096) / threads);
             uint64_t b0, i0, b1, i1;
             rph_pdq_batcher_stats(ctx, &b0, &i0);
