@@ -316,6 +316,41 @@ size_t rph_coeff_record_encode(const float *coeffs, size_t n_coeffs, uint8_t *ou
 int rph_coeff_record_decode(const uint8_t *rec, size_t len, float *coeffs_out, size_t cap, size_t *n_out);
 
 /* =====================================================================
+ * JPEG decode feeding the hasher.  Replaces the "jpg" | "jpeg" arm of load_image_fast
+ * (reference: src/scanner.rs:461-508: zune-jpeg 0.5.15 -> Luma8 for one component, Rgb8 for three) followed by
+ * generate_pdq_features (scanner.rs:1410).  The host undoes the entropy coding (one image per host thread, like the
+ * reference's rayon workers, scanner.rs:1202); dequantisation, IDCT, chroma upsampling, colour conversion, luma and
+ * the hash run on the device, a batch of files per launch, and only the hashes come back.
+ * Supported: baseline / extended sequential / progressive Huffman JPEG, 8 bit, 1 or 3 components, luma sampling
+ * 1x1, 2x1, 1x2, 2x2 with 1x1 chroma, restart intervals.  Anything else (CMYK, arithmetic coding, 12 bit, lossless)
+ * returns RPH_ERR_UNSUPPORTED and a corrupt stream RPH_ERR_INVALID_ARG -- the caller falls through to its next
+ * decoder exactly as the reference falls from tier 1 to tier 2 (scanner.rs:510-551).
+ * `flavour`: the sample arithmetic behind the (decoder independent) coefficients.
+ *   RPH_JPEG_ZUNE     what zune-jpeg does, as far as it can be restated without its source (absent from the reference
+ *                     tree): PARITY UNPINNED against the Rust binary.
+ *   RPH_JPEG_LIBJPEG  libjpeg-turbo's default arithmetic (islow IDCT, fancy upsampling): byte-identical to
+ *                     libjpeg-turbo / Pillow, which is what the tests pin it with.
+ * ===================================================================== */
+#define RPH_JPEG_ZUNE 0
+#define RPH_JPEG_LIBJPEG 1
+/* Frame header only, host code: width, height and 1 or 3 channels (what zune's info() gives load_image_fast, scanner.rs:477-481). */
+int rph_jpeg_info(const uint8_t *data, size_t len, uint32_t *w, uint32_t *h, uint32_t *channels);
+/* The host half alone (tests, tools): quantised coefficients in natural order, component-major, raster over each component's
+ * MCU-padded block grid.  geometry: 8 words per component {blocks_w, blocks_h, H, V, table, samples_w, samples_h, first_block};
+ * qt: 4 x 64 quantisation tables in natural order; coef may be NULL to ask for *total_blocks only. */
+int rph_jpeg_coefficients(const uint8_t *data, size_t len, uint32_t *geometry, uint16_t *qt, int16_t *coef, size_t cap_blocks,
+                          uint64_t *total_blocks);
+/* load_image_fast for one JPEG: pixels_out receives w * h * channels bytes, packed rows (Luma8 or Rgb8). */
+int rph_jpeg_decode(rph_ctx *ctx, const uint8_t *data, size_t len, int flavour, uint8_t *pixels_out);
+/* n files -> n hashes (optional quality / 256 coefficients / 8 dihedral hashes per file, as rph_pdq_hash_batch).
+ * n_threads host threads undo the entropy coding (0 = all hardware threads).  valid_out[i] = 0 and status_out[i] != RPH_OK
+ * for a file that cannot be decoded (the call itself still returns RPH_OK); valid_out[i] = 0 with status RPH_OK for an
+ * image below 5 px (generate_pdq_features' None, pdqhash.rs:167-169).  Files of any mix of sizes share a call. */
+int rph_jpeg_pdq_hash_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint32_t n, int flavour, uint32_t n_threads,
+                            uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *dihedral_out, uint8_t *valid_out,
+                            int32_t *status_out);
+
+/* =====================================================================
  * 64-bit pHash bit operations (reference: src/phash.rs:137-255), host scalar
  * ===================================================================== */
 uint64_t rph_phash_rotate_90(uint64_t hash);            /* phash.rs:150 */

@@ -18,6 +18,9 @@ RPH_ERR_OOM = -4
 RPH_ERR_UNSUPPORTED = -5
 RPH_ERR_CAPACITY = -6
 
+RPH_JPEG_ZUNE = 0
+RPH_JPEG_LIBJPEG = 1
+
 RPH_EDGE_MIH_R1 = 0x8000
 RPH_EDGE_PROBE_MASK = 0x01FF
 RPH_EDGE_VARIANT_SHIFT = 9
@@ -100,6 +103,11 @@ SIGNATURES = {
     "rph_coeff_record_size": (_sz, [_sz]),
     "rph_coeff_record_encode": (_sz, [_f32p, _sz, _u8p, _sz]),
     "rph_coeff_record_decode": (C.c_int, [_u8p, _sz, _f32p, _sz, C.POINTER(C.c_size_t)]),
+    "rph_jpeg_info": (C.c_int, [C.c_char_p, _sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rph_jpeg_coefficients": (C.c_int, [C.c_char_p, _sz, _u32p, _vp, _vp, _sz, C.POINTER(C.c_uint64)]),
+    "rph_jpeg_decode": (C.c_int, [_vp, C.c_char_p, _sz, C.c_int, _u8p]),
+    "rph_jpeg_pdq_hash_batch": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_uint32, C.c_int, C.c_uint32, _u8p, _f32p, _f32p,
+                                          _u8p, _u8p, _i32p]),
     "rph_phash_rotate_90": (C.c_uint64, [C.c_uint64]),
     "rph_phash_rotate_180": (C.c_uint64, [C.c_uint64]),
     "rph_phash_rotate_270": (C.c_uint64, [C.c_uint64]),

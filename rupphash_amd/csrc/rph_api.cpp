@@ -270,6 +270,7 @@ int rph_shutdown(rph_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     rph_pipe_forget(ctx);
     rph_resize_forget(ctx);
+    rph_jpeg_forget(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto &kv : ctx->ll_scratch) (void)hipFree(kv.second.p);
     if (ctx->sink) (void)hipFree(ctx->sink);

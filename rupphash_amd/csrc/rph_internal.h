@@ -51,6 +51,9 @@ struct rph_ctx {
     // 512x512 RGB8: 0 = always generic; 1 / 2 = fused one-wave-per-image kernel (64- / 128-px strips); 3 = fused low-latency kernel (eight
     // waves per image); 4 = automatic: low-latency below 768 images per call, one-wave-per-image (64-px strips) from there
     int pdq_kernel = 4;
+    // JPEG path (jpeg_kernels.hip): two chunk slots (pinned staging, device buffers, stream), kept across calls; one batch call at a time
+    std::mutex jpeg_mu;
+    void *jpeg = nullptr;
 };
 
 void rph_set_error(const char *fmt, ...);
@@ -123,6 +126,8 @@ int rph_pdq_hash_batch_keep(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_
 void rph_batcher_forget(rph_ctx *ctx);
 // resize_kernels.hip
 void rph_resize_forget(rph_ctx *ctx);
+// jpeg_kernels.hip
+void rph_jpeg_forget(rph_ctx *ctx);
 
 // host_grouping.cpp
 int rph_host_union_find(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,

@@ -98,6 +98,53 @@ class Engine:
             return None
         return hash32, q.value, coeffs
 
+    # ---- JPEG (scanner.rs:461-508) ----
+    @staticmethod
+    def jpeg_info(data):
+        """(w, h, channels) from the frame header (host code), or raises RphError (RPH_ERR_UNSUPPORTED / RPH_ERR_INVALID_ARG)."""
+        w, h, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(_lib.load().rph_jpeg_info(data, len(data), C.byref(w), C.byref(h), C.byref(c)), "rph_jpeg_info")
+        return w.value, h.value, c.value
+
+    @staticmethod
+    def jpeg_coefficients(data):
+        """The host half alone: (geometry[ncomp][8], qt[4][64], coef[total_blocks][64]) -- quantised coefficients in natural order."""
+        L = _lib.load()
+        _, _, c = Engine.jpeg_info(data)
+        geo = np.zeros((3, 8), np.uint32)
+        qt = np.zeros((4, 64), np.uint16)
+        total = C.c_uint64()
+        check(L.rph_jpeg_coefficients(data, len(data), _ptr(geo), _ptr(qt), None, 0, C.byref(total)), "rph_jpeg_coefficients")
+        coef = np.zeros((total.value, 64), np.int16)
+        check(L.rph_jpeg_coefficients(data, len(data), _ptr(geo), _ptr(qt), _ptr(coef), total.value, C.byref(total)), "rph_jpeg_coefficients")
+        return geo[:c], qt, coef
+
+    def jpeg_decode(self, data, flavour=0):
+        """load_image_fast for one JPEG byte string: (h, w) uint8 [Luma8] or (h, w, 3) [Rgb8], decoded on the device."""
+        w, h, c = self.jpeg_info(data)
+        out = np.zeros((h, w, 3) if c == 3 else (h, w), np.uint8)
+        check(self.L.rph_jpeg_decode(self.ctx, data, len(data), int(flavour), _ptr(out)), "rph_jpeg_decode")
+        return out
+
+    def jpeg_pdq_hash_batch(self, files, flavour=0, threads=0, want_quality=True, want_coeffs=False, want_dihedral=False):
+        """files: list of JPEG byte strings (any mix of sizes).  Returns dict(hash, quality, coeffs, dihedral, valid, status):
+        valid[i] = 0 with status[i] != 0 for a file that cannot be decoded, valid[i] = 0 with status 0 for an image below 5 px."""
+        n = len(files)
+        arr = (C.c_char_p * n)(*files)
+        lens = (C.c_size_t * n)(*[len(f) for f in files])
+        out = {
+            "hash": np.zeros((n, 32), np.uint8),
+            "quality": np.zeros(n, np.float32) if want_quality else None,
+            "coeffs": np.zeros((n, 256), np.float32) if want_coeffs else None,
+            "dihedral": np.zeros((n, 8, 32), np.uint8) if want_dihedral else None,
+            "valid": np.zeros(n, np.uint8),
+            "status": np.zeros(n, np.int32),
+        }
+        check(self.L.rph_jpeg_pdq_hash_batch(self.ctx, arr, lens, n, int(flavour), int(threads), _ptr(out["hash"]), _ptr(out["quality"]),
+                                             _ptr(out["coeffs"]), _ptr(out["dihedral"]), _ptr(out["valid"]), _ptr(out["status"])),
+              "rph_jpeg_pdq_hash_batch")
+        return out
+
     def pdq_batcher_config(self, max_batch=256, max_wait_us=0):
         check(self.L.rph_pdq_batcher_config(self.ctx, max_batch, max_wait_us), "rph_pdq_batcher_config")
 

@@ -1,0 +1,198 @@
+"""Test helpers for the JPEG path: generated test images, Pillow encodes, and a small baseline JPEG *encoder* for the
+sampling layouts Pillow cannot write (4:4:0 = 1x2 luma, all components 2x2, custom restart intervals, 16-bit tables).
+Data generation only -- nothing here decodes."""
+import io
+
+import numpy as np
+
+ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35,
+                   42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
+
+# ITU-T T.81 Annex K.3 typical Huffman tables
+DC_L = ([0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0], list(range(12)))
+DC_C = ([0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0], list(range(12)))
+AC_L = ([0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d],
+        [0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1,
+         0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26,
+         0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56,
+         0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85,
+         0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa,
+         0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+         0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+         0xfa])
+AC_C = ([0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77],
+        [0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42,
+         0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19,
+         0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55,
+         0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83,
+         0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8,
+         0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4,
+         0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+         0xfa])
+
+
+def make_image(w, h, mode="RGB", seed=1):
+    """smooth structure + noise, so that DC, low and high AC coefficients, EOBs and ZRLs all occur; returns a PIL image"""
+    from PIL import Image
+
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    base = np.stack([(np.sin(x / 7.0 + c) + np.cos(y / 5.0 - c)) * 60 + 128 for c in range(3)], -1)
+    a = np.clip(base + rng.normal(0, 25, (h, w, 3)), 0, 255).astype(np.uint8)
+    im = Image.fromarray(a, "RGB")
+    return im.convert("L") if mode == "L" else im
+
+
+def pillow_jpeg(im, **kw):
+    buf = io.BytesIO()
+    im.save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def pillow_decode(data):
+    from PIL import Image
+
+    return np.array(Image.open(io.BytesIO(data)))
+
+
+def _codes(counts, symbols):
+    table, code, k = {}, 0, 0
+    for length in range(1, 17):
+        for _ in range(counts[length - 1]):
+            table[symbols[k]] = (code, length)
+            code += 1
+            k += 1
+        code <<= 1
+    return table
+
+
+class _Bits:
+    def __init__(self):
+        self.out = bytearray()
+        self.acc = 0
+        self.n = 0
+
+    def put(self, value, nbits):
+        self.acc = (self.acc << nbits) | (value & ((1 << nbits) - 1))
+        self.n += nbits
+        while self.n >= 8:
+            b = (self.acc >> (self.n - 8)) & 0xFF
+            self.out.append(b)
+            if b == 0xFF:
+                self.out.append(0)
+            self.n -= 8
+
+    def flush(self):
+        if self.n:
+            self.put((1 << (8 - self.n)) - 1, 8 - self.n)
+
+
+def _fdct_blocks(plane):
+    """plane (multiple of 8 both ways, float) -> (by, bx, 8, 8) DCT-II coefficients, JPEG normalisation"""
+    k = np.arange(8)
+    c = np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16) * 0.5
+    c[0] *= 1 / np.sqrt(2)
+    h, w = plane.shape
+    b = plane.reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3) - 128.0
+    return np.einsum("ux,abxy,vy->abuv", c, b, c)
+
+
+def encode_baseline(rgb, sampling=((1, 2), (1, 1), (1, 1)), quality_scale=1.0, restart_interval=0, gray=False, sixteen_bit_tables=False):
+    """A plain baseline (SOF0) encoder: rgb (h, w, 3) uint8 [or (h, w) when gray]; sampling = (H, V) per component.
+    Chroma is box-averaged down.  Returns the JPEG byte string."""
+    rgb = np.asarray(rgb)
+    if gray:
+        h, w = rgb.shape
+        comps = [rgb.astype(np.float64)]
+        sampling = ((1, 1),)
+    else:
+        h, w, _ = rgb.shape
+        r, g, b = [rgb[..., i].astype(np.float64) for i in range(3)]
+        comps = [0.299 * r + 0.587 * g + 0.114 * b, -0.168736 * r - 0.331264 * g + 0.5 * b + 128, 0.5 * r - 0.418688 * g - 0.081312 * b + 128]
+    hmax = max(s[0] for s in sampling)
+    vmax = max(s[1] for s in sampling)
+    mcus_x = -(-w // (8 * hmax))
+    mcus_y = -(-h // (8 * vmax))
+    ql = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62, 18, 22,
+                   37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99])
+    qc = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32)
+    top = 65535 if sixteen_bit_tables else 255
+    qts = [np.clip(np.round(q * quality_scale), 1, top).astype(np.int64) for q in (ql, qc)]
+    blocks = []
+    for ci, (plane, (H, V)) in enumerate(zip(comps, sampling)):
+        fx, fy = hmax // H, vmax // V
+        pw, ph = mcus_x * 8 * hmax, mcus_y * 8 * vmax
+        full = np.pad(plane, ((0, ph - h), (0, pw - w)), mode="edge")
+        small = full.reshape(ph // fy, fy, pw // fx, fx).mean(axis=(1, 3))
+        q = qts[0 if ci == 0 else 1].reshape(8, 8)
+        blocks.append(np.round(_fdct_blocks(small) / q).astype(np.int64))
+    out = bytearray(b"\xff\xd8")
+
+    def seg(marker, payload):
+        out.extend(bytes([0xFF, marker]) + (len(payload) + 2).to_bytes(2, "big") + payload)
+
+    for t, q in enumerate(qts if not gray else qts[:1]):
+        zz = q[ZIGZAG]
+        seg(0xDB, bytes([(0x10 if sixteen_bit_tables else 0) | t]) + (b"".join(int(v).to_bytes(2, "big") for v in zz) if sixteen_bit_tables else bytes(int(v) for v in zz)))
+    sof = bytes([8]) + h.to_bytes(2, "big") + w.to_bytes(2, "big") + bytes([len(comps)])
+    for ci, (H, V) in enumerate(sampling):
+        sof += bytes([ci + 1, (H << 4) | V, 0 if ci == 0 else 1])
+    seg(0xC0, sof)
+    tables = [(0x00, DC_L), (0x10, AC_L)] + ([] if gray else [(0x01, DC_C), (0x11, AC_C)])
+    for tid, (counts, symbols) in tables:
+        seg(0xC4, bytes([tid]) + bytes(counts) + bytes(symbols))
+    if restart_interval:
+        seg(0xDD, restart_interval.to_bytes(2, "big"))
+    sos = bytes([len(comps)])
+    for ci in range(len(comps)):
+        sos += bytes([ci + 1, 0x00 if ci == 0 else 0x11])
+    seg(0xDA, sos + bytes([0, 63, 0]))
+    dc_codes = [_codes(*DC_L), _codes(*DC_C)]
+    ac_codes = [_codes(*AC_L), _codes(*AC_C)]
+    bits = _Bits()
+    pred = [0] * len(comps)
+
+    def put_block(blk, ci):
+        t = 0 if ci == 0 else 1
+        zz = blk.reshape(64)[ZIGZAG]
+        diff = int(zz[0]) - pred[ci]
+        pred[ci] = int(zz[0])
+        s = abs(diff).bit_length()
+        bits.put(*dc_codes[t][s])
+        if s:
+            bits.put(diff if diff >= 0 else diff + (1 << s) - 1, s)
+        run = 0
+        last = np.nonzero(zz[1:])[0]
+        end = (last[-1] + 1) if len(last) else 0
+        for k in range(1, end + 1):
+            v = int(zz[k])
+            if v == 0:
+                run += 1
+                continue
+            while run > 15:
+                bits.put(*ac_codes[t][0xF0])
+                run -= 16
+            s = abs(v).bit_length()
+            bits.put(*ac_codes[t][(run << 4) | s])
+            bits.put(v if v >= 0 else v + (1 << s) - 1, s)
+            run = 0
+        if end < 63:
+            bits.put(*ac_codes[t][0x00])
+
+    count, rst = 0, 0
+    for my in range(mcus_y):
+        for mx in range(mcus_x):
+            if restart_interval and count and count % restart_interval == 0:
+                bits.flush()
+                bits.out.extend(bytes([0xFF, 0xD0 + (rst & 7)]))
+                rst += 1
+                pred = [0] * len(comps)
+            for ci, (H, V) in enumerate(sampling):
+                for v in range(V):
+                    for hh in range(H):
+                        put_block(blocks[ci][my * V + v, mx * H + hh], ci)
+            count += 1
+    bits.flush()
+    out.extend(bits.out)
+    out.extend(b"\xff\xd9")
+    return bytes(out)

@@ -91,6 +91,9 @@ def lib():
         L.rph_ref_sbs_clear.argtypes = [C.c_void_p]
         L.rph_ref_sbs_free.argtypes = [C.c_void_p]
         L.rph_ref_target_dimensions.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+        L.rph_ref_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, u32p, u32p, u32p]
+        L.rph_ref_jpeg_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p]
+        L.rph_ref_jpeg_coefficients.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -395,3 +398,42 @@ def bench_find_groups(kind, hashes, max_dist, nthreads, q_limit=0):
         lib().rph_ref_free(mem)
         lib().rph_ref_free(off)
     return list(times), groups
+
+
+# ---------------- JPEG decode (row N3; oracle/jpeg_ref.c) ----------------
+JPEG_ZUNE, JPEG_LIBJPEG = 0, 1
+
+
+def jpeg_info(data):
+    """(w, h, channels) of a JPEG byte string, or raises ValueError(status)"""
+    w, h, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = lib().rph_ref_jpeg_info(data, len(data), C.byref(w), C.byref(h), C.byref(c))
+    if rc:
+        raise ValueError(rc)
+    return w.value, h.value, c.value
+
+
+def jpeg_decode(data, flavour=JPEG_ZUNE):
+    """decoded pixels: (h, w) uint8 for one component, (h, w, 3) for three"""
+    w, h, c = jpeg_info(data)
+    out = np.zeros((h, w, c) if c == 3 else (h, w), np.uint8)
+    rc = lib().rph_ref_jpeg_decode(data, len(data), int(flavour), _p(out))
+    if rc:
+        raise ValueError(rc)
+    return out
+
+
+def jpeg_coefficients(data):
+    """(geometry[ncomp][8], qt[4][64], coef[total_blocks][64]) -- quantised coefficients, natural order, component-major"""
+    _, _, c = jpeg_info(data)
+    geo = np.zeros((3, 8), np.uint32)
+    qt = np.zeros((4, 64), np.uint16)
+    total = C.c_uint64()
+    rc = lib().rph_ref_jpeg_coefficients(data, len(data), _p(geo), _p(qt), None, 0, C.byref(total))
+    if rc:
+        raise ValueError(rc)
+    coef = np.zeros((total.value, 64), np.int16)
+    rc = lib().rph_ref_jpeg_coefficients(data, len(data), _p(geo), _p(qt), _p(coef), total.value, C.byref(total))
+    if rc:
+        raise ValueError(rc)
+    return geo[:c], qt, coef
