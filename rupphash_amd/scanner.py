@@ -3,6 +3,7 @@
     PDQ_MIN_QUALITY, is_low_pdq_quality            scanner.rs:1588-1594
     group_with_pdqhash / group_files_generic       scanner.rs:1640-1832 up to the union-find
     group_max_dist                                 scanner.rs:2214-2241 (the per-group max_dist of process_raw_groups)
+    load_image_fast ("jpg" | "jpeg" arm)           scanner.rs:461-508
 File-name logic after the union-find (merge_groups_by_stem, the sorting inside process_raw_groups) stays with the caller.
 """
 import numpy as np
@@ -11,6 +12,19 @@ from . import _lib
 from .engine import default_engine
 
 PDQ_MIN_QUALITY = 50
+
+
+def load_image_fast(path, data, engine=None, flavour=_lib.RPH_JPEG_ZUNE):
+    """The "jpg" | "jpeg" arm of load_image_fast (scanner.rs:461-508): decoded on the device, returned as (h, w) uint8 [Luma8] or
+    (h, w, 3) [Rgb8] -- the DynamicImage the reference builds from zune-jpeg's buffer.  A stream the device path does not take
+    (CMYK, arithmetic coding, corrupt) raises RphError: the caller goes on to its next decoder, as the reference goes from tier 1 to
+    tier 2 (scanner.rs:510-551).  Every other extension is the host's business (ValueError)."""
+    import os
+
+    ext = os.path.splitext(str(path))[1].lstrip(".").lower()
+    if ext not in ("jpg", "jpeg"):
+        raise ValueError(f"load_image_fast: '{ext}' files are decoded by the host's decoders, not by this library")
+    return (engine or default_engine()).jpeg_decode(data, flavour)
 
 
 def is_low_pdq_quality(quality):

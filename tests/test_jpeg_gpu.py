@@ -1,0 +1,141 @@
+"""JPEG path on the GPU, through the C ABI: rph_jpeg_decode and rph_jpeg_pdq_hash_batch against the CPU oracle.
+
+Both arithmetic flavours are compared with oracle/jpeg_ref.c byte for byte; the LIBJPEG flavour additionally with Pillow
+(libjpeg-turbo) itself, which is the pin.  The ZUNE flavour (what the reference's zune-jpeg does, as recalled) is PARITY UNPINNED
+against the Rust binary: GPU == oracle is all that can be asserted.  Hashes: decode with the oracle, hash with the oracle's PDQ,
+compare with what the device produced from the file bytes (coefficients and quality bit patterns included)."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+import jpeg_util as ju
+
+pytestmark = pytest.mark.gpu
+PIL = pytest.importorskip("PIL")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FILES = ["bench.jpg", "Prophecy_Has_Been_Fulfilled_1.jpg", "Prophecy_Has_Been_Fulfilled_2.jpg"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from rupphash_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _read(name):
+    with open(os.path.join(GOLDEN, name), "rb") as f:
+        return f.read()
+
+
+def _oracle_hash(oracle, px):
+    """generate_pdq_features on decoded pixels: (valid, hash, quality, coeffs)"""
+    rc, coeffs, q = oracle.pdq_features(px)
+    if rc != 0:
+        return False, None, None, None
+    return True, oracle.to_hash(coeffs), np.float32(q), coeffs
+
+
+@pytest.mark.parametrize("name", FILES)
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_reference_files_decode_like_the_oracle(eng, oracle, name, flavour):
+    data = _read(name)
+    got = eng.jpeg_decode(data, flavour)
+    assert np.array_equal(got, oracle.jpeg_decode(data, flavour))
+    if flavour == 1:
+        assert np.array_equal(got, ju.pillow_decode(data))  # libjpeg-turbo itself
+
+
+def test_generated_streams_decode_like_the_oracle(eng, oracle):
+    sizes = [(1, 1), (3, 5), (8, 8), (15, 17), (17, 33), (100, 37), (129, 65), (250, 3), (3, 250), (640, 360)]
+    n = 0
+    for (w, h), (mode, ss), prog, (q, opt, rst) in itertools.product(sizes, [("RGB", 0), ("RGB", 1), ("RGB", 2), ("L", 0)], [False, True],
+                                                                     [(30, False, 0), (92, True, 3)]):
+        kw = dict(quality=q, progressive=prog, optimize=opt)
+        if mode == "RGB":
+            kw["subsampling"] = ss
+        if rst:
+            kw["restart_marker_blocks"] = rst
+        data = ju.pillow_jpeg(ju.make_image(w, h, mode, seed=n), **kw)
+        for flavour in (0, 1):
+            got = eng.jpeg_decode(data, flavour)
+            assert np.array_equal(got, oracle.jpeg_decode(data, flavour)), ((w, h), mode, ss, prog, q, flavour)
+        assert np.array_equal(got, ju.pillow_decode(data))
+        n += 1
+    layouts = [((2, 1), (1, 1), (1, 1)), ((1, 2), (1, 1), (1, 1)), ((2, 2), (1, 1), (1, 1)), ((2, 1), (2, 1), (2, 1)), ((1, 2), (1, 2), (1, 2))]
+    for (w, h), samp, (rst, qs, t16) in itertools.product([(16, 16), (33, 47), (100, 37), (7, 5), (2, 9)], layouts, [(0, 1.0, False), (5, 3.0, True)]):
+        data = ju.encode_baseline(np.array(ju.make_image(w, h)), samp, qs, rst, sixteen_bit_tables=t16)
+        for flavour in (0, 1):
+            assert np.array_equal(eng.jpeg_decode(data, flavour), oracle.jpeg_decode(data, flavour)), ((w, h), samp, flavour)
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_hash_batch_of_mixed_files_matches_decode_then_hash_on_the_cpu(eng, oracle, flavour):
+    """files of many geometries, gray and colour, below 5 px, above 512 px, 512x512 (fused kernel), undecodable: one call"""
+    files = [_read(n) for n in FILES]
+    synth = oracle.synth_images(998, 4)  # 512x512 RGB, one near-duplicate pair
+    from PIL import Image
+
+    for k in range(4):
+        files.append(ju.pillow_jpeg(Image.fromarray(synth[k]), quality=90, subsampling=[0, 2, 2, 1][k]))
+    specs = [(64, 64, "RGB", 2), (100, 37, "RGB", 1), (4, 30, "RGB", 0), (30, 4, "L", 0), (5, 5, "L", 0), (333, 512, "RGB", 2), (511, 509, "L", 0),
+             (700, 300, "RGB", 2), (129, 65, "RGB", 0), (512, 512, "L", 0)]
+    for i, (w, h, mode, ss) in enumerate(specs):
+        kw = dict(quality=85, progressive=bool(i & 1))
+        if mode == "RGB":
+            kw["subsampling"] = ss
+        files.append(ju.pillow_jpeg(ju.make_image(w, h, mode, seed=i), **kw))
+    files.insert(5, b"\xff\xd8 this is not a JPEG")
+    files.append(ju.pillow_jpeg(ju.make_image(16, 16).convert("CMYK")))
+    out = eng.jpeg_pdq_hash_batch(files, flavour=flavour, threads=4, want_quality=True, want_coeffs=True, want_dihedral=True)
+    for i, data in enumerate(files):
+        try:
+            px = oracle.jpeg_decode(data, flavour)
+        except ValueError:
+            assert out["status"][i] != 0 and out["valid"][i] == 0 and not out["hash"][i].any(), i
+            continue
+        assert out["status"][i] == 0, i
+        ok, h, q, c = _oracle_hash(oracle, px)
+        assert bool(out["valid"][i]) == ok, i
+        if ok:
+            assert np.array_equal(out["hash"][i], h), i
+            assert out["quality"][i].view(np.uint32) == q.view(np.uint32), i
+            assert np.array_equal(out["coeffs"][i].view(np.uint32), np.asarray(c, np.float32).view(np.uint32)), i
+            assert np.array_equal(out["dihedral"][i], oracle.dihedral_hashes(c)), i
+    # the near-duplicate pair of the synthetic stripe survives JPEG coding as near duplicates
+    assert oracle.hamming256(out["hash"][3], out["hash"][4]) <= 40  # files 3 and 4 are images 998 and 999 of the synthetic set
+
+
+def test_hash_batch_larger_than_one_chunk_and_thread_counts_agree(eng, oracle):
+    """~600 files of 512x512 cross the chunk boundary (double-buffered slots); 1, 3 and 16 host threads give the same bytes"""
+    from PIL import Image
+
+    synth = oracle.synth_images(0, 24)
+    base = [ju.pillow_jpeg(Image.fromarray(synth[k]), quality=80 + (k % 3) * 5, subsampling=2 * (k % 2), progressive=bool(k % 4 == 3)) for k in range(24)]
+    files = [base[k % 24] for k in range(600)]
+    ref = eng.jpeg_pdq_hash_batch(files, threads=16)
+    assert ref["valid"].all() and not ref["status"].any()
+    for k in range(24):
+        ok, h, q, _ = _oracle_hash(oracle, oracle.jpeg_decode(base[k], 0))
+        assert ok and np.array_equal(ref["hash"][k], h) and ref["quality"][k].view(np.uint32) == q.view(np.uint32)
+    for k in range(600):
+        assert np.array_equal(ref["hash"][k], ref["hash"][k % 24])
+    for t in (1, 3):
+        again = eng.jpeg_pdq_hash_batch(files[:100], threads=t)
+        assert np.array_equal(again["hash"], ref["hash"][:100])
+
+
+def test_scanner_load_image_fast_mirror(eng, oracle):
+    from rupphash_amd import scanner
+
+    data = _read("bench.jpg")
+    img = scanner.load_image_fast("x/y/bench.JPG", data, engine=eng)
+    assert img.shape == (854, 1280, 3) and np.array_equal(img, oracle.jpeg_decode(data, 0))
+    gray = ju.pillow_jpeg(ju.make_image(40, 30, "L"))
+    assert scanner.load_image_fast("g.jpeg", gray, engine=eng).shape == (30, 40)
+    with pytest.raises(ValueError):
+        scanner.load_image_fast("file.png", data, engine=eng)  # other formats stay with the host's decoders
