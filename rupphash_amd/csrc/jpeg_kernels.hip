@@ -183,7 +183,14 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t *__restric
         } else {
             idct_stb<65536 + (128 << 17), 17>(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
 #pragma unroll
-            for (int x = 0; x < 8; x++) v[x] = clamp8(r[x]);
+            for (int x = 0; x < 8; x++) {
+                // The value is made opaque between the shift and the clamp: ROCm 7.2's compiler otherwise fuses them into gfx950's
+                // v_ashr_pk_u8_i32 and ORs the other two bytes into its result as if the instruction cleared bits 16..31 -- it leaves
+                // them as they were (measured: bytes 2 and 3 of each dword came out wrong whenever the register's old value was not a byte)
+                int t = r[x];
+                asm("" : "+v"(t));
+                v[x] = clamp8(t);
+            }
         }
         uint2 w;
         w.x = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);

@@ -44,6 +44,10 @@ def make_image(w, h, mode="RGB", seed=1):
 
 
 def pillow_jpeg(im, **kw):
+    from PIL import ImageFile
+
+    # optimised / progressive encodes are written in one piece: the encoder's buffer must hold the whole (noisy, hence large) stream
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 8 * im.size[0] * im.size[1] + (1 << 16))
     buf = io.BytesIO()
     im.save(buf, "JPEG", **kw)
     return buf.getvalue()

@@ -54,7 +54,7 @@ def test_generated_streams_decode_like_the_oracle(eng, oracle):
     sizes = [(1, 1), (3, 5), (8, 8), (15, 17), (17, 33), (100, 37), (129, 65), (250, 3), (3, 250), (640, 360)]
     n = 0
     for (w, h), (mode, ss), prog, (q, opt, rst) in itertools.product(sizes, [("RGB", 0), ("RGB", 1), ("RGB", 2), ("L", 0)], [False, True],
-                                                                     [(30, False, 0), (92, True, 3)]):
+                                                                     [(30, False, 0), (92, True, 0), (75, False, 3)]):
         kw = dict(quality=q, progressive=prog, optimize=opt)
         if mode == "RGB":
             kw["subsampling"] = ss
