@@ -350,6 +350,18 @@ int rph_jpeg_pdq_hash_batch(rph_ctx *ctx, const uint8_t *const *data, const size
                             uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *dihedral_out, uint8_t *valid_out,
                             int32_t *status_out);
 
+/* Where rph_jpeg_pdq_hash_batch decodes the Huffman streams of sequential (baseline) files:
+ *   RPH_JPEG_ENTROPY_HOST (0)    n_threads host threads, one file each; the coefficients cross PCIe (0.8 MB per 512x512 file);
+ *   RPH_JPEG_ENTROPY_DEVICE (1)  on the device, one file per lane: the host only copies the entropy bytes (stuffing undone) and the
+ *                                compressed bytes cross PCIe; the walk of one file is serial (milliseconds), so this pays from
+ *                                thousands of files per call;
+ *   RPH_JPEG_ENTROPY_AUTO (2)    default: device from 2048 sequential files per call, host below.
+ * Progressive files are always decoded by the host threads.  Same results either way. */
+#define RPH_JPEG_ENTROPY_HOST 0
+#define RPH_JPEG_ENTROPY_DEVICE 1
+#define RPH_JPEG_ENTROPY_AUTO 2
+int rph_jpeg_set_entropy(rph_ctx *ctx, int where);
+
 /* =====================================================================
  * 64-bit pHash bit operations (reference: src/phash.rs:137-255), host scalar
  * ===================================================================== */

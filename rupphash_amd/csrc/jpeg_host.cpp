@@ -588,6 +588,156 @@ int parse_frame(const uint8_t *data, size_t len, Frame &f)
     return walk(data, len, f, nullptr);
 }
 
+int build_device_lut(const TableSpec &t, DeviceLut &out)
+{
+    memset(&out, 0, sizeof out);
+    memcpy(out.sym, t.symbols, t.total);
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; l++) {
+        out.delta[l] = k - code;
+        for (int i = 0; i < t.counts[l]; i++, k++, code++) {
+            if (code >= (1 << l)) return RPH_ERR_INVALID_ARG;
+            if (l <= 10) {
+                const int first = code << (10 - l), n = 1 << (10 - l);
+                for (int j = 0; j < n; j++) out.look[first + j] = (uint16_t)((l << 8) | t.symbols[k]);
+            }
+        }
+        out.maxcode[l] = code << (16 - l);
+        code <<= 1;
+    }
+    out.maxcode[17] = 0x7FFFFFFF;
+    return RPH_OK;
+}
+
+namespace {
+// entropy bytes of one scan, byte stuffing undone and RSTn dropped; returns the position of the marker that ends the scan
+const uint8_t *destuff(const uint8_t *p, const uint8_t *end, uint8_t *&out, uint8_t *out_end)
+{
+    while (p < end) {
+        const uint8_t *q = (const uint8_t *)memchr(p, 0xFF, (size_t)(end - p));
+        const size_t run = (size_t)((q ? q : end) - p);
+        if ((size_t)(out_end - out) < run + 1) return nullptr;
+        memcpy(out, p, run);
+        out += run;
+        if (!q) return end;
+        if (q + 1 >= end) return q;
+        const uint8_t m = q[1];
+        if (m == 0x00) {
+            *out++ = 0xFF;
+            p = q + 2;
+        } else if (m >= 0xD0 && m <= 0xD7) {
+            p = q + 2;  // restart marker: the decoder counts MCUs
+        } else if (m == 0xFF) {
+            p = q + 1;  // fill byte
+        } else {
+            return q;  // the marker that ends the scan
+        }
+    }
+    return end;
+}
+}  // namespace
+
+int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used)
+{
+    if (!f.have_sof || f.progressive) return RPH_ERR_UNSUPPORTED;
+    plan = StreamPlan();
+    TableSpec dc[4], ac[4];
+    bool dc_present[4] = {false, false, false, false}, ac_present[4] = {false, false, false, false};
+    for (int i = 0; i < 4; i++) f.qt_present[i] = false;
+    f.restart_interval = 0;
+    f.adobe_transform = -1;
+    uint8_t *o = out, *o_end = out + cap;
+    size_t pos = 2;
+    uint32_t done_mask = 0;
+    for (;;) {
+        while (pos < len && data[pos] != 0xFF) pos++;
+        while (pos < len && data[pos] == 0xFF) pos++;
+        if (pos >= len) break;
+        const int m = data[pos++];
+        if (m == 0xD9) break;
+        if (m == 0x00 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (pos + 2 > len) break;
+        const int n = rd16(data + pos) - 2;
+        const uint8_t *p = data + pos + 2;
+        if (n < 0 || pos + 2 + (size_t)n > len) break;
+        pos += 2 + (size_t)n;
+        switch (m) {
+        case 0xDB: {
+            const int rc = parse_dqt(f, p, n);
+            if (rc) return rc;
+            break;
+        }
+        case 0xC4: {
+            int left = n;
+            while (left > 0) {
+                if (left < 17) return RPH_ERR_INVALID_ARG;
+                const int tc = p[0] >> 4, th = p[0] & 15;
+                if (tc > 1 || th > 3) return RPH_ERR_INVALID_ARG;
+                TableSpec &t = tc ? ac[th] : dc[th];
+                int total = 0;
+                t.counts[0] = 0;
+                for (int l = 1; l <= 16; l++) {
+                    t.counts[l] = p[l];
+                    total += p[l];
+                }
+                if (total > 256 || left < 17 + total) return RPH_ERR_INVALID_ARG;
+                memset(t.symbols, 0, sizeof t.symbols);
+                memcpy(t.symbols, p + 17, (size_t)total);
+                t.total = (uint16_t)total;
+                (tc ? ac_present : dc_present)[th] = true;
+                p += 17 + total;
+                left -= 17 + total;
+            }
+            break;
+        }
+        case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+            return RPH_ERR_UNSUPPORTED;
+        case 0xDD:
+            if (n < 2) return RPH_ERR_INVALID_ARG;
+            f.restart_interval = (uint32_t)rd16(p);
+            break;
+        case 0xEE:
+            if (n >= 12 && memcmp(p, "Adobe", 5) == 0) f.adobe_transform = p[11];
+            break;
+        case 0xDA: {
+            if (plan.n_scans == 4) return RPH_ERR_UNSUPPORTED;
+            ScanPlan &sc = plan.scan[plan.n_scans];
+            if (n < 1) return RPH_ERR_INVALID_ARG;
+            sc.ns = p[0];
+            if (sc.ns < 1 || sc.ns > f.ncomp || n < 1 + 2 * sc.ns + 3) return RPH_ERR_INVALID_ARG;
+            for (int i = 0; i < sc.ns; i++) {
+                int c = 0;
+                while (c < f.ncomp && f.comp[c].id != p[1 + 2 * i]) c++;
+                if (c == f.ncomp || (done_mask >> c) & 1) return RPH_ERR_INVALID_ARG;  // a component is coded once in a sequential file
+                done_mask |= 1u << c;
+                sc.ci[i] = (uint8_t)c;
+                const int td = p[2 + 2 * i] >> 4, ta = p[2 + 2 * i] & 15;
+                if (td > 3 || ta > 3 || !dc_present[td] || !ac_present[ta]) return RPH_ERR_INVALID_ARG;
+                sc.dc[i] = dc[td];
+                sc.ac[i] = ac[ta];
+            }
+            sc.restart_interval = f.restart_interval;
+            sc.stream_off = (uint32_t)(o - out);
+            const uint8_t *stop = destuff(data + pos, data + len, o, o_end);
+            if (!stop || (size_t)(o_end - o) < 16) return RPH_ERR_CAPACITY;
+            sc.stream_len = (uint32_t)(o - out) - sc.stream_off;
+            memset(o, 0, 16);
+            o += 16;
+            pos = (size_t)(stop - data);
+            plan.n_scans++;
+            break;
+        }
+        default: break;
+        }
+    }
+    if (plan.n_scans == 0 || done_mask != (1u << f.ncomp) - 1) return RPH_ERR_INVALID_ARG;
+    if (f.ncomp == 3 && f.adobe_transform == 0) return RPH_ERR_UNSUPPORTED;
+    for (int c = 0; c < f.ncomp; c++)
+        if (!f.qt_present[f.comp[c].tq]) return RPH_ERR_INVALID_ARG;
+    *used = (size_t)(o - out);
+    return RPH_OK;
+}
+
 int decode_coefficients(const uint8_t *data, size_t len, Frame &f, int16_t *coef)
 {
     if (!f.have_sof || !coef) return RPH_ERR_INVALID_ARG;

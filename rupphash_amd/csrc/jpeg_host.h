@@ -40,4 +40,39 @@ int parse_frame(const uint8_t *data, size_t len, Frame &f);
 // the same bytes (its quantisation tables are completed here: a DQT may follow the frame header).
 int decode_coefficients(const uint8_t *data, size_t len, Frame &f, int16_t *coef);
 
+// ---- device entropy decoding (jpeg_kernels.hip: one image per lane): what the host prepares for it -------------------------------
+// A Huffman table as the device reads it: 10-bit lookup (code length << 8 | symbol, 0 = longer code), and the canonical-code arrays
+// for the rare longer codes.
+struct DeviceLut {
+    uint16_t look[1024];
+    int32_t maxcode[18];  // exclusive upper bound of the codes of each length in a 16-bit window
+    int32_t delta[17];    // symbol index = (window >> (16 - length)) + delta[length]
+    uint8_t sym[256];
+    uint8_t pad[4];
+};
+static_assert(sizeof(DeviceLut) % 16 == 0, "tables are packed in one array");
+
+struct TableSpec {  // a DHT entry as it stands in the file: the key tables are de-duplicated by
+    uint8_t counts[17];
+    uint8_t symbols[256];
+    uint16_t total = 0;
+};
+struct ScanPlan {
+    uint32_t stream_off = 0, stream_len = 0;  // de-stuffed entropy bytes of the scan in the job's stream buffer
+    uint32_t restart_interval = 0;            // as defined when the scan starts
+    uint8_t ns = 0, ci[3] = {0, 0, 0};
+    TableSpec dc[3], ac[3];                   // per component of the scan, as defined when the scan starts
+};
+struct StreamPlan {
+    int n_scans = 0;
+    ScanPlan scan[4];
+};
+
+// Sequential (SOF0 / SOF1) files only.  Walks the markers of a file whose frame `f` came from parse_frame, copies the entropy-coded
+// bytes of each scan to `out` with the byte stuffing undone (0xFF00 -> 0xFF) and the RSTn markers dropped (the decoder byte-aligns
+// every restart_interval MCUs instead), 16 zero bytes after each scan; at most `cap` bytes (len + 64 always suffices).
+// RPH_ERR_UNSUPPORTED: progressive, or more than 4 scans -- the caller uses decode_coefficients for that file.
+int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used);
+int build_device_lut(const TableSpec &t, DeviceLut &out);
+
 }  // namespace rphj

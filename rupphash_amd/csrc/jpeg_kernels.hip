@@ -293,6 +293,183 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const uint8_t *__restri
     d32[2] = px[8] | (px[9] << 8) | (px[10] << 16) | (px[11] << 24);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Entropy decoding on the device: ONE IMAGE PER LANE.
+//
+// A Huffman-coded scan is a serial bit stream, so a single image cannot be spread over lanes -- but a scan of a photo collection is
+// hundreds of thousands of independent streams.  Each lane walks its own image symbol by symbol as a small state machine (DC / AC
+// symbol, position in the block, block in the MCU, MCU in the scan); all lanes of a wave execute the same step, so there is no
+// divergence beyond the rare long code.  The host only copies the entropy bytes to pinned memory with the byte stuffing undone and
+// the RSTn markers dropped (jpeg_host.cpp: memchr + memcpy speed), so what crosses PCIe is the COMPRESSED file (a few tens of KB
+// instead of 0.8 MB of coefficients), and the quantised coefficients are born in HBM.  Lanes are ordered by stream length so the
+// images of a wave finish together.  Sequential (baseline) files only: a progressive file revisits every block in up to ten scans
+// and stays with the host decoder.  Latency per image is milliseconds (the walk is serial), so this is the path for large batches
+// only (rph_jpeg_set_entropy).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct HComp {
+    uint32_t blocks_w, real_bw, real_bh, first_block;
+    uint32_t H, V;
+};
+struct HScan {
+    uint32_t off, len, restart_interval, ns;
+    uint32_t ci[3];
+    uint32_t dc[3], ac[3];  // indices into the chunk's table array
+};
+struct HImage {
+    uint64_t first_block;  // of the image in the chunk's coefficient buffer
+    uint64_t stream_base;  // of the image's de-stuffed entropy bytes in the chunk's stream buffer
+    uint32_t mcus_x, mcus_y, n_scans, ncomp;
+    HComp comp[3];
+    HScan scan[4];
+};
+
+__constant__ uint8_t c_zigzag[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
+                                     6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
+                                     39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+
+template <class T>
+__device__ __forceinline__ T sel3(uint32_t i, T a, T b, T c)
+{
+    return i == 0 ? a : (i == 1 ? b : c);
+}
+
+__global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const uint32_t *__restrict__ order, uint32_t n,
+                                                       const rphj::DeviceLut *__restrict__ luts, int16_t *__restrict__ coef, uint8_t *__restrict__ status)
+{
+    __shared__ uint8_t zz[80];
+    for (int t = threadIdx.x; t < 80; t += 64) zz[t] = c_zigzag[t];
+    __syncthreads();
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n) return;
+    const uint32_t ii = order[slot];
+    const HImage *im = imgs + ii;
+    const uint64_t img_fb = im->first_block;
+    uint32_t bad = 0;
+    const uint32_t n_scans = im->n_scans;
+    for (uint32_t sc = 0; sc < n_scans && !bad; sc++) {
+        const HScan *S = &im->scan[sc];
+        const uint32_t ns = S->ns, ri = S->restart_interval;
+        // the scan's components (scan order); a single-component scan walks the component's own block grid (T.81 A.2.2)
+        uint32_t H0, H1, H2, V0, V1, V2, BW0, BW1, BW2, FB0, FB1, FB2;
+        const rphj::DeviceLut *D0, *D1, *D2, *A0, *A1, *A2;
+        {
+            const HComp *c0 = &im->comp[S->ci[0]], *c1 = &im->comp[S->ci[ns > 1 ? 1 : 0]], *c2 = &im->comp[S->ci[ns > 2 ? 2 : 0]];
+            H0 = ns == 1 ? 1 : c0->H, V0 = ns == 1 ? 1 : c0->V, BW0 = c0->blocks_w, FB0 = c0->first_block;
+            H1 = c1->H, V1 = c1->V, BW1 = c1->blocks_w, FB1 = c1->first_block;
+            H2 = c2->H, V2 = c2->V, BW2 = c2->blocks_w, FB2 = c2->first_block;
+            D0 = luts + S->dc[0], A0 = luts + S->ac[0];
+            D1 = luts + S->dc[ns > 1 ? 1 : 0], A1 = luts + S->ac[ns > 1 ? 1 : 0];
+            D2 = luts + S->dc[ns > 2 ? 2 : 0], A2 = luts + S->ac[ns > 2 ? 2 : 0];
+        }
+        const uint32_t MX = ns == 1 ? im->comp[S->ci[0]].real_bw : im->mcus_x, MY = ns == 1 ? im->comp[S->ci[0]].real_bh : im->mcus_y;
+        const uint32_t per_mcu = H0 * V0 + (ns > 1 ? H1 * V1 : 0) + (ns > 2 ? H2 * V2 : 0);
+        const uint64_t max_it = (uint64_t)MX * MY * per_mcu * 65 + 8;  // a block takes at most 1 + 63 symbols: the walk always ends
+        // bit reader: `off` bytes of the scan consumed into acc (MSB first), nb valid bits
+        const uint8_t *sp = streams + im->stream_base + S->off;
+        const uint32_t slen = S->len;
+        uint32_t off = 0;
+        uint64_t acc = 0;
+        int nb = 0;
+        // position: component i of the MCU, block (h, v) of the component, MCU (mx, my); k = next coefficient index (zigzag order)
+        uint32_t i = 0, h = 0, v = 0, mx = 0, my = 0, k = 0, until = ri;
+        uint32_t Hc = H0, Vc = V0, BWc = BW0, FBc = FB0;
+        const rphj::DeviceLut *DCc = D0, *ACc = A0;
+        int p0 = 0, p1 = 0, p2 = 0;
+        bool is_dc = true, done = MX == 0 || MY == 0;
+        uint64_t base = (img_fb + FBc) * 64;
+        for (uint64_t it = 0; !done && it < max_it; it++) {
+            if (nb < 32) {  // 4 more bytes (the 16 zero bytes behind the scan make the look-ahead safe; a corrupt stream reads zeros there for ever)
+                const uint32_t o = off < slen + 8 ? off : slen + 8;
+                const uintptr_t a = (uintptr_t)(sp + o);
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+                const uint32_t dw = __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(a & 3));
+                acc |= (uint64_t)__builtin_bswap32(dw) << (32 - nb);
+                nb += 32;
+                off += 4;
+            }
+            const rphj::DeviceLut *L = is_dc ? DCc : ACc;
+            const uint32_t e = L->look[(uint32_t)(acc >> 54)];
+            uint32_t len, sym;
+            if (e) {
+                len = e >> 8;
+                sym = e & 255;
+            } else {  // a code longer than 10 bits
+                const int32_t win = (int32_t)(acc >> 48);
+                uint32_t l = 11;
+                while (l <= 16 && win >= L->maxcode[l]) l++;
+                if (l > 16) {
+                    bad = 1;
+                    break;
+                }
+                len = l;
+                sym = L->sym[(uint32_t)((win >> (16 - l)) + L->delta[l]) & 255];
+            }
+            acc <<= len;
+            nb -= (int)len;
+            const uint32_t s = is_dc ? sym : (sym & 15), r = is_dc ? 0 : (sym >> 4);
+            if (s > 15) {
+                bad = 1;
+                break;
+            }
+            int val = 0;
+            if (s) {  // s more bits: the value, T.81 F.2.2.1 EXTEND
+                const uint32_t raw = (uint32_t)(acc >> (64 - s));
+                acc <<= s;
+                nb -= (int)s;
+                val = raw < (1u << (s - 1)) ? (int)raw - (int)((1u << s) - 1) : (int)raw;
+            }
+            if (is_dc) {
+                const int pv = sel3(i, p0, p1, p2) + val;
+                p0 = i == 0 ? pv : p0;
+                p1 = i == 1 ? pv : p1;
+                p2 = i == 2 ? pv : p2;
+                coef[base] = (int16_t)pv;
+                k = 1;
+                is_dc = false;
+            } else if (s == 0) {
+                k = r == 15 ? k + 16 : 64;  // ZRL, or end of block
+            } else {
+                k += r;
+                coef[base + zz[k < 79 ? k : 79]] = (int16_t)val;
+                k++;
+            }
+            if (k >= 64) {  // next block
+                is_dc = true;
+                k = 0;
+                if (++h == Hc) {
+                    h = 0;
+                    if (++v == Vc) {
+                        v = 0;
+                        if (++i == ns) {
+                            i = 0;
+                            if (ri && --until == 0) {  // restart interval: drop the padding bits, reset the predictions (the marker itself is gone)
+                                const int drop = nb & 7;
+                                acc <<= drop;
+                                nb -= drop;
+                                p0 = p1 = p2 = 0;
+                                until = ri;
+                            }
+                            if (++mx == MX) {
+                                mx = 0;
+                                if (++my == MY) done = true;
+                            }
+                        }
+                        Hc = sel3(i, H0, H1, H2);
+                        Vc = sel3(i, V0, V1, V2);
+                        BWc = sel3(i, BW0, BW1, BW2);
+                        FBc = sel3(i, FB0, FB1, FB2);
+                        DCc = sel3(i, D0, D1, D2);
+                        ACc = sel3(i, A0, A1, A2);
+                    }
+                }
+                base = (img_fb + FBc + (uint64_t)(my * Vc + v) * BWc + (mx * Hc + h)) * 64;
+            }
+        }
+        if (!done) bad = 1;
+    }
+    status[ii] = (uint8_t)bad;
+}
+
 #define RPH_TRY(expr)                  \
     do {                               \
         int rc_ = (expr);              \
@@ -301,85 +478,138 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const uint8_t *__restri
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// A pinned host buffer with its device twin, grown on demand (the caller has synchronised the stream that used it)
+struct Twin {
+    uint8_t *h = nullptr, *d = nullptr;
+    size_t cap = 0;
+    void release()
+    {
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        h = d = nullptr;
+        cap = 0;
+    }
+    int reserve(size_t bytes, bool host = true, bool dev = true)
+    {
+        if (cap >= bytes) return RPH_OK;
+        release();
+        bytes = align_up(bytes + bytes / 4, 4096);
+        if (host) RPH_HIP_CHECK(hipHostMalloc((void **)&h, bytes));
+        if (dev) RPH_HIP_CHECK(hipMalloc((void **)&d, bytes));
+        cap = bytes;
+        return RPH_OK;
+    }
+};
+
+constexpr size_t RES_BYTES = 32 + 4 + 1024 + 256 + 4;  // per image: hash, quality, coefficients, dihedral, valid + entropy status (padded)
+struct ResView {  // the per-image result arrays inside one buffer laid out for `images` images
+    uint8_t *hash, *quality, *coeffs, *dihedral, *valid, *status;
+    ResView(uint8_t *p, size_t images)
+    {
+        hash = p;
+        quality = hash + images * 32;
+        coeffs = quality + images * 4;
+        dihedral = coeffs + images * 1024;
+        valid = dihedral + images * 256;
+        status = valid + images;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------------
-// The chunk pipeline: two slots (pinned staging + device buffers + stream), so the host threads decode chunk k + 1 while the device
-// works on chunk k.  Kept in the context across calls; one JPEG batch call per context at a time (ctx->jpeg_mu).
+// The pipeline.  One JPEG batch call per context at a time (ctx->jpeg_mu); buffers are kept in the context across calls.
+//   host entropy:   chunks of <= 192 MB of coefficients, two slots: the host threads decode chunk k + 1 while the device works on k
+//   device entropy: chunks as large as the coefficient buffer allows (tens of thousands of images: one per lane), the host only
+//                   prepares streams; reconstruction + hashing then runs over the chunk in sub-batches through small buffers
 // ---------------------------------------------------------------------------------------------------------------------------
 struct Slot {
     hipStream_t stream = nullptr;
-    // host (pinned)
-    int16_t *h_coef = nullptr;
-    uint8_t *h_desc = nullptr;  // planes | images | tables
-    uint8_t *h_res = nullptr;   // hash | quality | coeffs | dihedral | valid
-    // device
-    int16_t *d_coef = nullptr;
-    uint8_t *d_desc = nullptr, *d_planes = nullptr, *d_out = nullptr, *d_res = nullptr;
-    size_t coef_bytes = 0, desc_bytes = 0, res_images = 0;
+    hipEvent_t done = nullptr;  // device entropy: the slot's chunk (work on another slot's stream) has delivered its results
+    Twin coef;              // host entropy: pinned staging + device; device entropy: unused
+    Twin stream_bytes;      // device entropy: de-stuffed entropy bytes
+    Twin meta;              // descriptors (planes | images | tables | HImage | order | DeviceLut)
+    Twin res;               // results
+    size_t res_images = 0;
     void release()
     {
         if (stream) (void)hipStreamSynchronize(stream);
-        for (void *p : {(void *)h_coef, (void *)h_desc, (void *)h_res})
-            if (p) (void)hipHostFree(p);
-        for (void *p : {(void *)d_coef, (void *)d_desc, (void *)d_planes, (void *)d_out, (void *)d_res})
-            if (p) (void)hipFree(p);
+        coef.release();
+        stream_bytes.release();
+        meta.release();
+        res.release();
         if (stream) (void)hipStreamDestroy(stream);
+        if (done) (void)hipEventDestroy(done);
         *this = Slot();
     }
-    // capacity for `coef_need` bytes of coefficients and `images` images
-    int reserve(size_t coef_need, size_t images)
+    int ready()
     {
         if (!stream) RPH_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        if (coef_bytes < coef_need) {
-            RPH_HIP_CHECK(hipStreamSynchronize(stream));
-            for (void *p : {(void *)h_coef})
-                if (p) (void)hipHostFree(p);
-            for (void *p : {(void *)d_coef, (void *)d_planes, (void *)d_out})
-                if (p) (void)hipFree(p);
-            h_coef = nullptr, d_coef = nullptr, d_planes = nullptr, d_out = nullptr, coef_bytes = 0;
-            RPH_HIP_CHECK(hipHostMalloc((void **)&h_coef, coef_need));
-            RPH_HIP_CHECK(hipMalloc((void **)&d_coef, coef_need));
-            RPH_HIP_CHECK(hipMalloc((void **)&d_planes, coef_need / 2 + 256));  // 64 bytes of samples per 128 bytes of coefficients
-            // packed pixels never exceed the coefficient bytes (4:2:0: both 3 w h; Luma8: w h against 2 w h), plus row / image padding
-            RPH_HIP_CHECK(hipMalloc((void **)&d_out, coef_need + coef_need / 8 + 4096));
-            coef_bytes = coef_need;
-        }
-        if (res_images < images) {
-            RPH_HIP_CHECK(hipStreamSynchronize(stream));
-            for (void *p : {(void *)h_desc, (void *)h_res})
-                if (p) (void)hipHostFree(p);
-            for (void *p : {(void *)d_desc, (void *)d_res})
-                if (p) (void)hipFree(p);
-            h_desc = nullptr, h_res = nullptr, d_desc = nullptr, d_res = nullptr, res_images = 0;
-            desc_bytes = images * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128);
-            RPH_HIP_CHECK(hipHostMalloc((void **)&h_desc, desc_bytes));
-            RPH_HIP_CHECK(hipMalloc((void **)&d_desc, desc_bytes));
-            RPH_HIP_CHECK(hipHostMalloc((void **)&h_res, images * RES_BYTES));
-            RPH_HIP_CHECK(hipMalloc((void **)&d_res, images * RES_BYTES));
-            res_images = images;
-        }
+        if (!done) RPH_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
         return RPH_OK;
     }
-    static constexpr size_t RES_BYTES = 32 + 4 + 1024 + 256 + 4;  // per image: hash, quality, coefficients, dihedral, valid (padded)
+    int reserve_res(size_t images)  // the caller has made sure nothing in flight still uses the slot's buffers
+    {
+        if (res_images >= images) return RPH_OK;
+        RPH_HIP_CHECK(hipStreamSynchronize(stream));
+        images += images / 4;
+        RPH_TRY(res.reserve(images * RES_BYTES));
+        res_images = images;
+        return RPH_OK;
+    }
 };
 struct JpegPipe {
     Slot slot[2];
+    // reconstruction buffers (sample planes, packed pixels) shared by the slots' sub-batches: used in stream order, one sub-batch at a
+    // time per stream; each slot owns one pair
+    uint8_t *d_planes[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
+    size_t recon_coef_bytes[2] = {0, 0};
+    // device entropy: the chunk's coefficient buffer (one: chunks run back to back on one stream)
+    int16_t *d_coef = nullptr;
+    size_t d_coef_bytes = 0;
     void release()
     {
         slot[0].release();
         slot[1].release();
+        for (int b = 0; b < 2; b++) {
+            if (d_planes[b]) (void)hipFree(d_planes[b]);
+            if (d_out[b]) (void)hipFree(d_out[b]);
+            d_planes[b] = d_out[b] = nullptr;
+            recon_coef_bytes[b] = 0;
+        }
+        if (d_coef) (void)hipFree(d_coef);
+        d_coef = nullptr;
+        d_coef_bytes = 0;
+    }
+    // sample planes and packed pixels for sub-batches of up to `coef_need` bytes of coefficients
+    int reserve_recon(int b, size_t coef_need, hipStream_t s)
+    {
+        if (recon_coef_bytes[b] >= coef_need) return RPH_OK;
+        RPH_HIP_CHECK(hipStreamSynchronize(s));
+        if (d_planes[b]) (void)hipFree(d_planes[b]);
+        if (d_out[b]) (void)hipFree(d_out[b]);
+        d_planes[b] = d_out[b] = nullptr;
+        recon_coef_bytes[b] = 0;
+        RPH_HIP_CHECK(hipMalloc((void **)&d_planes[b], coef_need / 2 + 256));  // 64 bytes of samples per 128 bytes of coefficients
+        // packed pixels never exceed the coefficient bytes (4:2:0: both 3 w h; Luma8: w h against 2 w h), plus row / image padding
+        RPH_HIP_CHECK(hipMalloc((void **)&d_out[b], coef_need + coef_need / 8 + 65536));
+        recon_coef_bytes[b] = coef_need;
+        return RPH_OK;
     }
 };
 
-constexpr size_t CHUNK_COEF_BYTES = (size_t)192 << 20;   // per slot: ~250 images of 512x512 4:2:0
+constexpr size_t CHUNK_COEF_BYTES = (size_t)192 << 20;   // host entropy, per slot: ~250 images of 512x512 4:2:0
+constexpr size_t SUB_COEF_BYTES = (size_t)1 << 30;        // device entropy: reconstruction sub-batch (~1300 such images)
 constexpr size_t MAX_IMAGE_COEF_BYTES = (size_t)3 << 30;  // one image beyond this is refused (RPH_ERR_UNSUPPORTED)
-constexpr uint32_t CHUNK_MAX_IMAGES = 4096;
+constexpr uint32_t CHUNK_MAX_IMAGES = 4096;               // host entropy
+constexpr uint32_t DEVICE_ENTROPY_MIN_FILES = 2048;       // automatic mode: below this the host decodes (latency)
 
 struct Job {
     const uint8_t *data = nullptr;
     size_t len = 0;
     rphj::Frame frame;
     int status = RPH_OK;
-    uint64_t first_block = 0;  // within the chunk
+    uint64_t first_block = 0;  // within the chunk's coefficient buffer
+    rphj::StreamPlan plan;     // device entropy
+    size_t stream_off = 0, stream_used = 0;
 };
 
 size_t out_bytes_of(const rphj::Frame &f)
@@ -388,20 +618,18 @@ size_t out_bytes_of(const rphj::Frame &f)
     return align_up(stride * f.h, 64);
 }
 
-// decode jobs [first, last) on `threads` host threads into the slot's staging buffer
-void decode_chunk(std::vector<Job> &jobs, size_t first, size_t last, int16_t *h_coef, unsigned threads)
+template <class F>
+void parallel_for(size_t first, size_t last, unsigned threads, F &&body)
 {
     std::atomic<size_t> next{first};
     auto work = [&]() {
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= last) return;
-            Job &j = jobs[i];
-            if (j.status != RPH_OK) continue;
-            j.status = rphj::decode_coefficients(j.data, j.len, j.frame, h_coef + j.first_block * 64);
+            body(i);
         }
     };
-    const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, threads), last - first);
+    const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, threads), last > first ? last - first : 1);
     if (nt <= 1) {
         work();
         return;
@@ -423,6 +651,414 @@ struct Outputs {
     bool want_hash = true;
 };
 
+// Descriptors of the chunk idx[first..last) and where they live in the slot's meta buffer (host and device at the same offsets)
+struct ChunkDesc {
+    size_t m = 0;
+    size_t off_planes = 0, off_images = 0, off_tables = 0, off_end = 0;
+    std::vector<uint32_t> image_of, plane_of;  // per chunk position: index of its JImage / first JPlane (UINT32_MAX: not decodable)
+    std::vector<uint32_t> n_blocks;            // per chunk position
+    uint32_t n_planes = 0, n_images = 0;
+};
+
+// Sub-batch boundaries are where the offsets of planes and pixels restart from 0: `sub_of[r]` = first chunk position of r's sub-batch.
+int build_descriptors(std::vector<Job> &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, int flavour, size_t sub_coef_bytes, uint8_t *h_meta, size_t meta_base,
+                      ChunkDesc &D, std::vector<size_t> &sub_starts)
+{
+    const size_t m = last - first;
+    D.m = m;
+    D.off_planes = meta_base;
+    D.off_images = D.off_planes + m * 3 * sizeof(JPlane);
+    D.off_tables = D.off_images + m * sizeof(JImage);
+    D.off_end = D.off_tables + m * 3 * 128;
+    JPlane *hp = reinterpret_cast<JPlane *>(h_meta + D.off_planes);
+    JImage *hi = reinterpret_cast<JImage *>(h_meta + D.off_images);
+    uint16_t *hq = reinterpret_cast<uint16_t *>(h_meta + D.off_tables);
+    D.image_of.assign(m, UINT32_MAX);
+    D.plane_of.assign(m, UINT32_MAX);
+    D.n_blocks.assign(m, 0);
+    D.n_planes = D.n_images = 0;
+    sub_starts.clear();
+    sub_starts.push_back(0);
+    size_t plane_bytes = 0, out_bytes = 0, sub_blocks = 0;
+    for (size_t r = 0; r < m; r++) {
+        Job &j = jobs[idx[first + r]];
+        if (j.status != RPH_OK) continue;
+        const rphj::Frame &f = j.frame;
+        if (sub_blocks && (sub_blocks + f.total_blocks) * 128 > sub_coef_bytes) {  // the sub-batch is full: offsets restart
+            sub_starts.push_back(r);
+            plane_bytes = out_bytes = sub_blocks = 0;
+        }
+        sub_blocks += f.total_blocks;
+        D.n_blocks[r] = (uint32_t)f.total_blocks;
+        JImage im;
+        memset(&im, 0, sizeof im);
+        D.plane_of[r] = D.n_planes;
+        for (int c = 0; c < f.ncomp; c++) {
+            const rphj::Comp &kc = f.comp[c];
+            JPlane pl;
+            pl.first_block = j.first_block + kc.first_block;
+            pl.out_off = plane_bytes;
+            pl.blocks_w = kc.blocks_w;
+            pl.blocks_h = kc.blocks_h;
+            pl.qt = D.n_planes;
+            pl.pitch = kc.blocks_w * 8;
+            memcpy(hq + (size_t)D.n_planes * 64, f.qt[kc.tq], 128);
+            im.plane_off[c] = plane_bytes;
+            im.pitch[c] = pl.pitch;
+            plane_bytes += (size_t)pl.pitch * kc.blocks_h * 8;
+            hp[D.n_planes++] = pl;
+        }
+        im.w = f.w;
+        im.h = f.h;
+        im.ncomp = (uint32_t)f.ncomp;
+        im.hs = im.vs = 1;
+        if (f.ncomp == 3) {
+            im.hs = f.comp[0].H / f.comp[1].H;
+            im.vs = f.comp[0].V / f.comp[1].V;
+            im.cw = flavour == RPH_JPEG_LIBJPEG ? f.comp[1].samp_w : f.comp[1].blocks_w * 8;
+            im.ch = flavour == RPH_JPEG_LIBJPEG ? f.comp[1].samp_h : f.comp[1].blocks_h * 8;
+        }
+        im.out_stride = (uint32_t)((size_t)f.ncomp * align_up(f.w, 4));
+        im.out_off = out_bytes;
+        out_bytes += out_bytes_of(f);
+        D.image_of[r] = D.n_images;
+        hi[D.n_images++] = im;
+    }
+    return RPH_OK;
+}
+
+// IDCT + upsampling / colour + hashing of chunk positions [r0, r1) (one sub-batch: its planes and pixels fit the slot's reconstruction buffers)
+int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, std::vector<Job> &jobs, const std::vector<uint32_t> &idx, size_t first, const ChunkDesc &D, size_t r0,
+                         size_t r1, const int16_t *d_coef, int flavour, const Outputs &out, hipStream_t s)
+{
+    // the planes and images of the sub-batch are contiguous in the descriptor arrays
+    uint32_t p0 = UINT32_MAX, p1 = 0, i0 = UINT32_MAX, i1 = 0, max_blocks = 0, max_groups = 0;
+    for (size_t r = r0; r < r1; r++) {
+        if (D.image_of[r] == UINT32_MAX) continue;
+        const rphj::Frame &f = jobs[idx[first + r]].frame;
+        p0 = std::min(p0, D.plane_of[r]);
+        p1 = std::max(p1, D.plane_of[r] + (uint32_t)f.ncomp);
+        i0 = std::min(i0, D.image_of[r]);
+        i1 = std::max(i1, D.image_of[r] + 1);
+        for (int c = 0; c < f.ncomp; c++) max_blocks = std::max(max_blocks, f.comp[c].blocks_w * f.comp[c].blocks_h);
+        max_groups = std::max<uint32_t>(max_groups, (uint32_t)(((f.w + 3) / 4) * (size_t)f.h));
+    }
+    if (i0 == UINT32_MAX) return RPH_OK;
+    const JPlane *dp = reinterpret_cast<const JPlane *>(S.meta.d + D.off_planes) + p0;
+    const JImage *di = reinterpret_cast<const JImage *>(S.meta.d + D.off_images) + i0;
+    const uint16_t *dq = reinterpret_cast<const uint16_t *>(S.meta.d + D.off_tables);
+    const dim3 gi((max_blocks + 255) / 256, p1 - p0), gc((max_groups + 255) / 256, i1 - i0);
+    if (flavour == RPH_JPEG_LIBJPEG) {
+        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_LIBJPEG>, gi, dim3(256), 0, s, d_coef, dq, dp, P.d_planes[b]);
+        hipLaunchKernelGGL(jpeg_color_kernel<RPH_JPEG_LIBJPEG>, gc, dim3(256), 0, s, P.d_planes[b], di, P.d_out[b]);
+    } else {
+        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_ZUNE>, gi, dim3(256), 0, s, d_coef, dq, dp, P.d_planes[b]);
+        hipLaunchKernelGGL(jpeg_color_kernel<RPH_JPEG_ZUNE>, gc, dim3(256), 0, s, P.d_planes[b], di, P.d_out[b]);
+    }
+    RPH_HIP_CHECK(hipGetLastError());
+    if (!out.want_hash) return RPH_OK;
+    // hash runs of equal geometry where the pixels lie (generate_pdq_features, scanner.rs:1410)
+    ResView R(S.res.d, S.res_images);
+    const JImage *hi = reinterpret_cast<const JImage *>(S.meta.h + D.off_images);
+    for (size_t r = r0; r < r1;) {
+        if (D.image_of[r] == UINT32_MAX) {
+            r++;
+            continue;
+        }
+        const rphj::Frame &f = jobs[idx[first + r]].frame;
+        size_t e = r + 1;
+        while (e < r1 && D.image_of[e] != UINT32_MAX && jobs[idx[first + e]].frame.w == f.w && jobs[idx[first + e]].frame.h == f.h && jobs[idx[first + e]].frame.ncomp == f.ncomp) e++;
+        RPH_TRY(rph_pdq_hash_batch_dev(ctx, P.d_out[b] + hi[D.image_of[r]].out_off, (uint32_t)(e - r), f.w, f.h, (uint32_t)f.ncomp, (size_t)f.ncomp * align_up(f.w, 4), out_bytes_of(f),
+                                       R.hash + r * 32, out.quality ? R.quality + r * 4 : nullptr, out.coeffs ? R.coeffs + r * 1024 : nullptr,
+                                       out.dihedral ? R.dihedral + r * 256 : nullptr, R.valid + r, s));
+        r = e;
+    }
+    return RPH_OK;
+}
+
+// results of a finished chunk -> the caller's arrays (scattered through idx)
+void scatter_results(const Slot &S, std::vector<Job> &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, const Outputs &out, bool entropy_status)
+{
+    ResView R(S.res.h, S.res_images);
+    for (size_t r = 0; r < last - first; r++) {
+        const uint32_t g = idx[first + r];
+        Job &j = jobs[g];
+        if (entropy_status && j.status == RPH_OK && R.status[r]) j.status = RPH_ERR_INVALID_ARG;  // the device walk met a corrupt stream
+        const bool ok = j.status == RPH_OK;
+        if (out.hash) ok ? (void)memcpy(out.hash + (size_t)g * 32, R.hash + r * 32, 32) : (void)memset(out.hash + (size_t)g * 32, 0, 32);
+        if (out.quality) ok ? (void)memcpy(out.quality + g, R.quality + r * 4, 4) : (void)memset(out.quality + g, 0, 4);
+        if (out.coeffs) ok ? (void)memcpy(out.coeffs + (size_t)g * 256, R.coeffs + r * 1024, 1024) : (void)memset(out.coeffs + (size_t)g * 256, 0, 1024);
+        if (out.dihedral) ok ? (void)memcpy(out.dihedral + (size_t)g * 256, R.dihedral + r * 256, 256) : (void)memset(out.dihedral + (size_t)g * 256, 0, 256);
+        if (out.valid) out.valid[g] = ok ? R.valid[r] : 0;
+    }
+}
+
+// ---- host entropy decoding: the files idx[...] in chunks over the two slots
+int run_host_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, const std::vector<uint32_t> &idx, int flavour, unsigned threads, const Outputs &out)
+{
+    struct Pending {
+        bool active = false;
+        size_t first = 0, last = 0;
+    } pend[2];
+    auto finish = [&](int b) -> int {
+        if (!pend[b].active) return RPH_OK;
+        RPH_HIP_CHECK(hipStreamSynchronize(P.slot[b].stream));
+        scatter_results(P.slot[b], jobs, idx, pend[b].first, pend[b].last, out, false);
+        pend[b].active = false;
+        return RPH_OK;
+    };
+    const size_t n = idx.size();
+    int k = 0;
+    for (size_t first = 0; first < n; k++) {
+        size_t last = first, blocks = 0;
+        while (last < n && last - first < CHUNK_MAX_IMAGES) {
+            const Job &j = jobs[idx[last]];
+            const size_t nb = j.status == RPH_OK ? (size_t)j.frame.total_blocks : 0;
+            if (last > first && (blocks + nb) * 128 > CHUNK_COEF_BYTES) break;
+            blocks += nb;
+            last++;
+        }
+        const int b = k & 1;
+        RPH_TRY(finish(b));
+        Slot &S = P.slot[b];
+        RPH_TRY(S.ready());
+        const size_t m = last - first;
+        const size_t coef_need = std::max(CHUNK_COEF_BYTES, blocks * 128);
+        if (S.coef.cap < coef_need) {
+            RPH_HIP_CHECK(hipStreamSynchronize(S.stream));
+            RPH_TRY(S.coef.reserve(coef_need));
+        }
+        RPH_TRY(P.reserve_recon(b, coef_need, S.stream));
+        RPH_TRY(S.reserve_res(std::max<size_t>(m, std::min<size_t>(n, CHUNK_MAX_IMAGES))));
+        const size_t meta_need = std::max<size_t>(m, std::min<size_t>(n, CHUNK_MAX_IMAGES)) * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128);
+        if (S.meta.cap < meta_need) {
+            RPH_HIP_CHECK(hipStreamSynchronize(S.stream));
+            RPH_TRY(S.meta.reserve(meta_need));
+        }
+        {
+            uint64_t fb = 0;
+            for (size_t i = first; i < last; i++) {
+                Job &j = jobs[idx[i]];
+                j.first_block = fb;
+                if (j.status == RPH_OK) fb += j.frame.total_blocks;
+            }
+        }
+        int16_t *h_coef = reinterpret_cast<int16_t *>(S.coef.h);
+        parallel_for(first, last, threads, [&](size_t i) {
+            Job &j = jobs[idx[i]];
+            if (j.status == RPH_OK) j.status = rphj::decode_coefficients(j.data, j.len, j.frame, h_coef + j.first_block * 64);
+        });
+        ChunkDesc D;
+        std::vector<size_t> subs;
+        RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, SIZE_MAX / 256, S.meta.h, 0, D, subs));
+        hipStream_t s = S.stream;
+        RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
+        if (D.n_images) {
+            RPH_HIP_CHECK(hipMemcpyAsync(S.coef.d, S.coef.h, blocks * 128, hipMemcpyHostToDevice, s));
+            RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, D.off_end, hipMemcpyHostToDevice, s));
+            RPH_TRY(reconstruct_and_hash(ctx, P, b, S, jobs, idx, first, D, 0, m, reinterpret_cast<const int16_t *>(S.coef.d), flavour, out, s));
+        }
+        if (out.want_hash) RPH_HIP_CHECK(hipMemcpyAsync(S.res.h, S.res.d, S.res_images * RES_BYTES, hipMemcpyDeviceToHost, s));
+        if (out.pixels && m == 1 && jobs[idx[first]].status == RPH_OK) {  // single-image decode: rows without their padding
+            const rphj::Frame &f = jobs[idx[first]].frame;
+            const size_t row = (size_t)f.ncomp * f.w, stride = (size_t)f.ncomp * align_up(f.w, 4);
+            RPH_HIP_CHECK(hipMemcpy2DAsync(out.pixels, row, P.d_out[b], stride, row, f.h, hipMemcpyDeviceToHost, s));
+        }
+        pend[b].active = true;
+        pend[b].first = first;
+        pend[b].last = last;
+        first = last;
+    }
+    RPH_TRY(finish(k & 1));
+    RPH_TRY(finish((k + 1) & 1));
+    return RPH_OK;
+}
+
+// ---- device entropy decoding: the sequential files idx[...]; files the device walk does not take come back in `leftover` for the host
+int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::vector<uint32_t> idx, int flavour, unsigned threads, const Outputs &out,
+                       std::vector<uint32_t> &leftover)
+{
+    // images of similar stream length share a wave: sort the whole list by file length first (chunks then are slices of it)
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return jobs[a].len > jobs[b].len; });
+    // the chunk's coefficient buffer: as much of the free device memory as is reasonable, but no more than this call can use
+    size_t need = 0;
+    for (uint32_t g : idx) need += (size_t)jobs[g].frame.total_blocks * 128;
+    size_t free_b = 0, total_b = 0;
+    RPH_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = std::max<size_t>((size_t)1 << 30, std::min<size_t>((free_b + P.d_coef_bytes) / 2, (size_t)96 << 30));
+    const size_t want = std::min(need, budget);
+    if (P.d_coef_bytes < want) {
+        RPH_HIP_CHECK(hipDeviceSynchronize());
+        if (P.d_coef) (void)hipFree(P.d_coef);
+        P.d_coef = nullptr;
+        P.d_coef_bytes = 0;
+        RPH_HIP_CHECK(hipMalloc((void **)&P.d_coef, want));
+        P.d_coef_bytes = want;
+    }
+    struct Pending {
+        bool active = false;
+        size_t first = 0, last = 0;
+    } pend[2];
+    auto finish = [&](int b) -> int {
+        if (!pend[b].active) return RPH_OK;
+        RPH_HIP_CHECK(hipEventSynchronize(P.slot[b].done));  // every chunk runs on slot 0's stream (they share the coefficient buffer)
+        scatter_results(P.slot[b], jobs, idx, pend[b].first, pend[b].last, out, true);
+        pend[b].active = false;
+        return RPH_OK;
+    };
+    RPH_TRY(P.slot[0].ready());
+    RPH_TRY(P.slot[1].ready());
+    hipStream_t s = P.slot[0].stream;
+    {
+        size_t max_img = 0;  // a sub-batch holds at least one image
+        for (uint32_t g : idx) max_img = std::max(max_img, (size_t)jobs[g].frame.total_blocks * 128);
+        RPH_TRY(P.reserve_recon(0, std::max(std::min(SUB_COEF_BYTES, std::max(want, (size_t)64 << 20)), max_img), s));
+    }
+    const size_t n = idx.size();
+    int k = 0;
+    for (size_t first = 0; first < n; k++) {
+        size_t last = first, blocks = 0, file_bytes = 0;
+        while (last < n) {
+            const Job &j = jobs[idx[last]];
+            const size_t nb = (size_t)j.frame.total_blocks;
+            if (last > first && (blocks + nb) * 128 > P.d_coef_bytes) break;
+            blocks += nb;
+            file_bytes += align_up(j.len + 64, 16);
+            last++;
+        }
+        if (blocks * 128 > P.d_coef_bytes) {  // one image larger than the whole buffer: the host path takes it
+            leftover.push_back(idx[first]);
+            first = last;
+            k--;
+            continue;
+        }
+        const int b = k & 1;
+        RPH_TRY(finish(b));  // the staging of this slot is free again once its chunk (two chunks back) is done
+        Slot &S = P.slot[b];
+        const size_t m = last - first;
+        RPH_TRY(S.reserve_res(m));
+        RPH_TRY(S.stream_bytes.reserve(file_bytes + 64));
+        // ---- streams and scan plans (host threads: memchr + memcpy)
+        {
+            size_t off = 0;
+            uint64_t fb = 0;
+            for (size_t i = first; i < last; i++) {
+                Job &j = jobs[idx[i]];
+                j.stream_off = off;
+                off += align_up(j.len + 64, 16);
+                j.first_block = fb;
+                fb += j.frame.total_blocks;
+            }
+        }
+        parallel_for(first, last, threads, [&](size_t i) {
+            Job &j = jobs[idx[i]];
+            j.status = rphj::prepare_stream(j.data, j.len, j.frame, j.plan, S.stream_bytes.h + j.stream_off, align_up(j.len + 64, 16), &j.stream_used);
+        });
+        // files the walk does not take (more than four scans) go back to the host decoder; they keep their place in the chunk as holes
+        for (size_t i = first; i < last; i++) {
+            Job &j = jobs[idx[i]];
+            if (j.status == RPH_ERR_UNSUPPORTED || j.status == RPH_ERR_CAPACITY) leftover.push_back(idx[i]);
+        }
+        // ---- tables (de-duplicated by content), image records, lane order
+        std::vector<rphj::DeviceLut> luts;
+        std::vector<std::pair<uint64_t, uint32_t>> seen;  // (content hash, index): collisions are resolved by comparing the specs
+        std::vector<const rphj::TableSpec *> spec_of;
+        auto lut_of = [&](const rphj::TableSpec &t) -> uint32_t {
+            uint64_t hsh = 1469598103934665603ULL;
+            for (int q = 1; q <= 16; q++) hsh = (hsh ^ t.counts[q]) * 1099511628211ULL;
+            for (int q = 0; q < t.total; q++) hsh = (hsh ^ t.symbols[q]) * 1099511628211ULL;
+            for (auto &e : seen)
+                if (e.first == hsh && spec_of[e.second]->total == t.total && memcmp(spec_of[e.second]->counts, t.counts, 17) == 0 &&
+                    memcmp(spec_of[e.second]->symbols, t.symbols, t.total) == 0)
+                    return e.second;
+            rphj::DeviceLut L;
+            if (rphj::build_device_lut(t, L) != RPH_OK) return UINT32_MAX;
+            luts.push_back(L);
+            spec_of.push_back(&t);
+            seen.emplace_back(hsh, (uint32_t)luts.size() - 1);
+            return (uint32_t)luts.size() - 1;
+        };
+        std::vector<HImage> himgs(m);
+        std::vector<uint32_t> order;
+        order.reserve(m);
+        for (size_t r = 0; r < m; r++) {
+            Job &j = jobs[idx[first + r]];
+            HImage &hi = himgs[r];
+            memset(&hi, 0, sizeof hi);
+            if (j.status != RPH_OK) continue;
+            const rphj::Frame &f = j.frame;
+            hi.first_block = j.first_block;
+            hi.stream_base = j.stream_off;
+            hi.mcus_x = f.mcus_x;
+            hi.mcus_y = f.mcus_y;
+            hi.n_scans = (uint32_t)j.plan.n_scans;
+            hi.ncomp = (uint32_t)f.ncomp;
+            for (int c = 0; c < f.ncomp; c++) {
+                const rphj::Comp &kc = f.comp[c];
+                hi.comp[c] = HComp{kc.blocks_w, kc.real_bw, kc.real_bh, (uint32_t)kc.first_block, kc.H, kc.V};
+            }
+            bool ok = true;
+            for (int q = 0; q < j.plan.n_scans && ok; q++) {
+                const rphj::ScanPlan &sp = j.plan.scan[q];
+                HScan &hs = hi.scan[q];
+                hs.off = sp.stream_off;
+                hs.len = sp.stream_len;
+                hs.restart_interval = sp.restart_interval;
+                hs.ns = sp.ns;
+                for (int c = 0; c < sp.ns; c++) {
+                    hs.ci[c] = sp.ci[c];
+                    hs.dc[c] = lut_of(sp.dc[c]);
+                    hs.ac[c] = lut_of(sp.ac[c]);
+                    ok = ok && hs.dc[c] != UINT32_MAX && hs.ac[c] != UINT32_MAX;
+                }
+            }
+            if (!ok) {
+                j.status = RPH_ERR_INVALID_ARG;
+                continue;
+            }
+            order.push_back((uint32_t)r);
+        }
+        // ---- meta buffer: reconstruction descriptors | HImage | order | tables
+        const size_t recon_bytes = m * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128);
+        const size_t off_himg = align_up(recon_bytes, 16), off_order = off_himg + m * sizeof(HImage), off_luts = align_up(off_order + m * 4, 16),
+                     meta_bytes = off_luts + luts.size() * sizeof(rphj::DeviceLut);
+        RPH_TRY(S.meta.reserve(meta_bytes));
+        ChunkDesc D;
+        std::vector<size_t> subs;
+        RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, P.recon_coef_bytes[0], S.meta.h, 0, D, subs));
+        memcpy(S.meta.h + off_himg, himgs.data(), m * sizeof(HImage));
+        memcpy(S.meta.h + off_order, order.data(), order.size() * 4);
+        if (!luts.empty()) memcpy(S.meta.h + off_luts, luts.data(), luts.size() * sizeof(rphj::DeviceLut));
+        // ---- device: streams up, zeroed coefficients, the walk, then reconstruction + hashing sub-batch by sub-batch
+        ResView R(S.res.d, S.res_images);
+        RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
+        if (!order.empty()) {
+            RPH_HIP_CHECK(hipMemcpyAsync(S.stream_bytes.d, S.stream_bytes.h, file_bytes + 64, hipMemcpyHostToDevice, s));
+            RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, meta_bytes, hipMemcpyHostToDevice, s));
+            RPH_HIP_CHECK(hipMemsetAsync(P.d_coef, 0, blocks * 128, s));
+            hipLaunchKernelGGL(jpeg_huff_kernel, dim3(((uint32_t)order.size() + 63) / 64), dim3(64), 0, s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg),
+                               reinterpret_cast<const uint32_t *>(S.meta.d + off_order), (uint32_t)order.size(), reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts),
+                               P.d_coef, R.status);
+            RPH_HIP_CHECK(hipGetLastError());
+            for (size_t q = 0; q < subs.size(); q++) {
+                const size_t r0 = subs[q], r1 = q + 1 < subs.size() ? subs[q + 1] : m;
+                RPH_TRY(reconstruct_and_hash(ctx, P, 0, S, jobs, idx, first, D, r0, r1, P.d_coef, flavour, out, s));
+            }
+        }
+        RPH_HIP_CHECK(hipMemcpyAsync(S.res.h, S.res.d, S.res_images * RES_BYTES, hipMemcpyDeviceToHost, s));
+        RPH_HIP_CHECK(hipEventRecord(S.done, s));
+        pend[b].active = true;
+        pend[b].first = first;
+        pend[b].last = last;
+        first = last;
+    }
+    RPH_TRY(finish(k & 1));
+    RPH_TRY(finish((k + 1) & 1));
+    // files handed to the host decoder start over there
+    for (uint32_t g : leftover) jobs[g].status = RPH_OK;
+    return RPH_OK;
+}
+
 int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint32_t n, int flavour, uint32_t n_threads, Outputs out)
 {
     if (flavour != RPH_JPEG_ZUNE && flavour != RPH_JPEG_LIBJPEG) {
@@ -437,161 +1073,34 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
     threads = std::min(threads, 256u);
 
     std::vector<Job> jobs(n);
-    for (uint32_t i = 0; i < n; i++) {
+    parallel_for(0, n, n >= 1024 ? threads : 1, [&](size_t i) {
         Job &j = jobs[i];
         j.data = data[i];
         j.len = len[i];
         j.status = (j.data && j.len) ? rphj::parse_frame(j.data, j.len, j.frame) : RPH_ERR_INVALID_ARG;
         if (j.status == RPH_OK && j.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) j.status = RPH_ERR_UNSUPPORTED;
+    });
+    // which files walk their Huffman streams on the device: sequential ones, when the batch is large enough to fill lanes
+    std::vector<uint32_t> host_idx, dev_idx;
+    for (uint32_t i = 0; i < n; i++) {
+        const Job &j = jobs[i];
+        if (j.status == RPH_OK && !j.frame.progressive && ctx->jpeg_entropy != 0 && out.want_hash)
+            dev_idx.push_back(i);
+        else
+            host_idx.push_back(i);
     }
-
-    struct Pending {
-        bool active = false;
-        size_t first = 0, last = 0;
-    } pend[2];
-    auto finish = [&](int b) -> int {
-        if (!pend[b].active) return RPH_OK;
-        Slot &S = P.slot[b];
-        RPH_HIP_CHECK(hipStreamSynchronize(S.stream));
-        const size_t m = pend[b].last - pend[b].first, f0 = pend[b].first;
-        const uint8_t *r = S.h_res;
-        if (out.hash) memcpy(out.hash + f0 * 32, r, m * 32);
-        r += S.res_images * 32;
-        if (out.quality) memcpy(out.quality + f0, r, m * 4);
-        r += S.res_images * 4;
-        if (out.coeffs) memcpy(out.coeffs + f0 * 256, r, m * 1024);
-        r += S.res_images * 1024;
-        if (out.dihedral) memcpy(out.dihedral + f0 * 256, r, m * 256);
-        r += S.res_images * 256;
-        if (out.valid)
-            for (size_t i = 0; i < m; i++) out.valid[f0 + i] = jobs[f0 + i].status == RPH_OK ? r[i] : 0;
-        pend[b].active = false;
-        return RPH_OK;
-    };
-
-    int k = 0;
-    for (size_t first = 0; first < n; k++) {
-        // ---- the chunk: as many images as fit the staging buffer
-        size_t last = first, blocks = 0;
-        while (last < n && last - first < CHUNK_MAX_IMAGES) {
-            const Job &j = jobs[last];
-            const size_t nb = j.status == RPH_OK ? (size_t)j.frame.total_blocks : 0;
-            if (last > first && (blocks + nb) * 128 > CHUNK_COEF_BYTES) break;
-            blocks += nb;
-            last++;
-        }
-        const int b = k & 1;
-        RPH_TRY(finish(b));
-        Slot &S = P.slot[b];
-        RPH_TRY(S.reserve(std::max(CHUNK_COEF_BYTES, blocks * 128), std::max<size_t>(last - first, std::min<size_t>(n, CHUNK_MAX_IMAGES))));
-        {
-            uint64_t fb = 0;
-            for (size_t i = first; i < last; i++) {
-                jobs[i].first_block = fb;
-                if (jobs[i].status == RPH_OK) fb += jobs[i].frame.total_blocks;
-            }
-        }
-        decode_chunk(jobs, first, last, S.h_coef, threads);
-
-        // ---- descriptors
-        const size_t m = last - first;
-        JPlane *hp = reinterpret_cast<JPlane *>(S.h_desc);
-        JImage *hi = reinterpret_cast<JImage *>(S.h_desc + m * 3 * sizeof(JPlane));
-        uint16_t *hq = reinterpret_cast<uint16_t *>(S.h_desc + m * (3 * sizeof(JPlane) + sizeof(JImage)));
-        uint32_t n_planes = 0, n_images = 0, max_blocks = 0, max_groups = 0;
-        size_t plane_bytes = 0, out_bytes = 0;
-        std::vector<uint32_t> image_of(m, UINT32_MAX);
-        std::vector<size_t> out_off(m, 0);
-        for (size_t i = first; i < last; i++) {
-            Job &j = jobs[i];
-            if (j.status != RPH_OK) continue;
-            const rphj::Frame &f = j.frame;
-            JImage im;
-            memset(&im, 0, sizeof im);
-            for (int c = 0; c < f.ncomp; c++) {
-                const rphj::Comp &kc = f.comp[c];
-                JPlane pl;
-                pl.first_block = j.first_block + kc.first_block;
-                pl.out_off = plane_bytes;
-                pl.blocks_w = kc.blocks_w;
-                pl.blocks_h = kc.blocks_h;
-                pl.qt = n_planes;
-                pl.pitch = kc.blocks_w * 8;
-                memcpy(hq + (size_t)n_planes * 64, f.qt[kc.tq], 128);
-                im.plane_off[c] = plane_bytes;
-                im.pitch[c] = pl.pitch;
-                plane_bytes += (size_t)pl.pitch * kc.blocks_h * 8;
-                max_blocks = std::max(max_blocks, kc.blocks_w * kc.blocks_h);
-                hp[n_planes++] = pl;
-            }
-            im.w = f.w;
-            im.h = f.h;
-            im.ncomp = (uint32_t)f.ncomp;
-            im.hs = im.vs = 1;
-            if (f.ncomp == 3) {
-                im.hs = f.comp[0].H / f.comp[1].H;
-                im.vs = f.comp[0].V / f.comp[1].V;
-                im.cw = flavour == RPH_JPEG_LIBJPEG ? f.comp[1].samp_w : f.comp[1].blocks_w * 8;
-                im.ch = flavour == RPH_JPEG_LIBJPEG ? f.comp[1].samp_h : f.comp[1].blocks_h * 8;
-            }
-            im.out_stride = (uint32_t)((size_t)f.ncomp * align_up(f.w, 4));
-            im.out_off = out_bytes;
-            out_off[i - first] = out_bytes;
-            out_bytes += out_bytes_of(f);
-            max_groups = std::max<uint32_t>(max_groups, (uint32_t)(((f.w + 3) / 4) * (size_t)f.h));
-            image_of[i - first] = n_images;
-            hi[n_images++] = im;
-        }
-        hipStream_t s = S.stream;
-        uint8_t *d_hash = S.d_res, *d_q = d_hash + S.res_images * 32, *d_c = d_q + S.res_images * 4, *d_d = d_c + S.res_images * 1024,
-                *d_v = d_d + S.res_images * 256;
-        RPH_HIP_CHECK(hipMemsetAsync(S.d_res, 0, S.res_images * Slot::RES_BYTES, s));
-        if (n_images) {
-            RPH_HIP_CHECK(hipMemcpyAsync(S.d_coef, S.h_coef, blocks * 128, hipMemcpyHostToDevice, s));
-            RPH_HIP_CHECK(hipMemcpyAsync(S.d_desc, S.h_desc, m * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128), hipMemcpyHostToDevice, s));
-            const JPlane *dp = reinterpret_cast<const JPlane *>(S.d_desc);
-            const JImage *di = reinterpret_cast<const JImage *>(S.d_desc + m * 3 * sizeof(JPlane));
-            const uint16_t *dq = reinterpret_cast<const uint16_t *>(S.d_desc + m * (3 * sizeof(JPlane) + sizeof(JImage)));
-            const dim3 gi((max_blocks + 255) / 256, n_planes), gc((max_groups + 255) / 256, n_images);
-            if (flavour == RPH_JPEG_LIBJPEG) {
-                hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_LIBJPEG>, gi, dim3(256), 0, s, S.d_coef, dq, dp, S.d_planes);
-                hipLaunchKernelGGL(jpeg_color_kernel<RPH_JPEG_LIBJPEG>, gc, dim3(256), 0, s, S.d_planes, di, S.d_out);
-            } else {
-                hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_ZUNE>, gi, dim3(256), 0, s, S.d_coef, dq, dp, S.d_planes);
-                hipLaunchKernelGGL(jpeg_color_kernel<RPH_JPEG_ZUNE>, gc, dim3(256), 0, s, S.d_planes, di, S.d_out);
-            }
-            RPH_HIP_CHECK(hipGetLastError());
-        }
-        // ---- hash runs of equal geometry where the pixels lie (generate_pdq_features, scanner.rs:1410)
-        if (out.want_hash) {
-            for (size_t i = first; i < last;) {
-                if (jobs[i].status != RPH_OK) {
-                    i++;
-                    continue;
-                }
-                const rphj::Frame &f = jobs[i].frame;
-                size_t e = i + 1;
-                while (e < last && jobs[e].status == RPH_OK && jobs[e].frame.w == f.w && jobs[e].frame.h == f.h && jobs[e].frame.ncomp == f.ncomp) e++;
-                const size_t r0 = i - first;
-                RPH_TRY(rph_pdq_hash_batch_dev(ctx, S.d_out + out_off[r0], (uint32_t)(e - i), f.w, f.h, (uint32_t)f.ncomp, (size_t)f.ncomp * align_up(f.w, 4),
-                                               out_bytes_of(f), d_hash + r0 * 32, out.quality ? d_q + r0 * 4 : nullptr, out.coeffs ? d_c + r0 * 1024 : nullptr,
-                                               out.dihedral ? d_d + r0 * 256 : nullptr, d_v + r0, s));
-                i = e;
-            }
-            RPH_HIP_CHECK(hipMemcpyAsync(S.h_res, S.d_res, S.res_images * Slot::RES_BYTES, hipMemcpyDeviceToHost, s));
-        }
-        if (out.pixels && m == 1 && jobs[first].status == RPH_OK) {  // single-image decode: rows without their padding
-            const rphj::Frame &f = jobs[first].frame;
-            const size_t row = (size_t)f.ncomp * f.w, stride = (size_t)f.ncomp * align_up(f.w, 4);
-            RPH_HIP_CHECK(hipMemcpy2DAsync(out.pixels, row, S.d_out, stride, row, f.h, hipMemcpyDeviceToHost, s));
-        }
-        pend[b].active = true;
-        pend[b].first = first;
-        pend[b].last = last;
-        first = last;
+    if (ctx->jpeg_entropy == 2 && dev_idx.size() < DEVICE_ENTROPY_MIN_FILES) {
+        host_idx.clear();
+        for (uint32_t i = 0; i < n; i++) host_idx.push_back(i);
+        dev_idx.clear();
     }
-    RPH_TRY(finish(k & 1));
-    RPH_TRY(finish((k + 1) & 1));
+    if (!dev_idx.empty()) {
+        std::vector<uint32_t> leftover;
+        RPH_TRY(run_device_entropy(ctx, P, jobs, dev_idx, flavour, threads, out, leftover));
+        host_idx.insert(host_idx.end(), leftover.begin(), leftover.end());
+        std::sort(host_idx.begin(), host_idx.end());
+    }
+    if (!host_idx.empty()) RPH_TRY(run_host_entropy(ctx, P, jobs, host_idx, flavour, threads, out));
     int worst = RPH_OK;
     for (uint32_t i = 0; i < n; i++) {
         if (out.status) out.status[i] = jobs[i].status;
@@ -668,6 +1177,17 @@ int rph_jpeg_coefficients(const uint8_t *data, size_t len, uint32_t *geometry, u
         memcpy(qt, f.qt, sizeof f.qt);
         return RPH_OK;
     });
+}
+
+int rph_jpeg_set_entropy(rph_ctx *ctx, int where)
+{
+    if (!ctx || where < 0 || where > 2) {
+        rph_set_error("rph_jpeg_set_entropy: invalid argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lock(ctx->jpeg_mu);
+    ctx->jpeg_entropy = where;
+    return RPH_OK;
 }
 
 int rph_jpeg_decode(rph_ctx *ctx, const uint8_t *data, size_t len, int flavour, uint8_t *pixels_out)

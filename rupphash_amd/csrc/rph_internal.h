@@ -54,6 +54,9 @@ struct rph_ctx {
     // JPEG path (jpeg_kernels.hip): two chunk slots (pinned staging, device buffers, stream), kept across calls; one batch call at a time
     std::mutex jpeg_mu;
     void *jpeg = nullptr;
+    // where the Huffman streams of sequential files are decoded: 0 = host threads, 1 = device (one image per lane), 2 = automatic
+    // (device from 2048 sequential files per call: the walk of one image is serial, so it needs tens of thousands of images in flight)
+    int jpeg_entropy = 2;
 };
 
 void rph_set_error(const char *fmt, ...);

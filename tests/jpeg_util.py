@@ -101,9 +101,10 @@ def _fdct_blocks(plane):
     return np.einsum("ux,abxy,vy->abuv", c, b, c)
 
 
-def encode_baseline(rgb, sampling=((1, 2), (1, 1), (1, 1)), quality_scale=1.0, restart_interval=0, gray=False, sixteen_bit_tables=False):
+def encode_baseline(rgb, sampling=((1, 2), (1, 1), (1, 1)), quality_scale=1.0, restart_interval=0, gray=False, sixteen_bit_tables=False, interleaved=True):
     """A plain baseline (SOF0) encoder: rgb (h, w, 3) uint8 [or (h, w) when gray]; sampling = (H, V) per component.
-    Chroma is box-averaged down.  Returns the JPEG byte string."""
+    Chroma is box-averaged down.  interleaved=False writes one scan per component (each over the component's own block grid,
+    T.81 A.2.2).  Returns the JPEG byte string."""
     rgb = np.asarray(rgb)
     if gray:
         h, w = rgb.shape
@@ -147,16 +148,11 @@ def encode_baseline(rgb, sampling=((1, 2), (1, 1), (1, 1)), quality_scale=1.0, r
         seg(0xC4, bytes([tid]) + bytes(counts) + bytes(symbols))
     if restart_interval:
         seg(0xDD, restart_interval.to_bytes(2, "big"))
-    sos = bytes([len(comps)])
-    for ci in range(len(comps)):
-        sos += bytes([ci + 1, 0x00 if ci == 0 else 0x11])
-    seg(0xDA, sos + bytes([0, 63, 0]))
     dc_codes = [_codes(*DC_L), _codes(*DC_C)]
     ac_codes = [_codes(*AC_L), _codes(*AC_C)]
-    bits = _Bits()
     pred = [0] * len(comps)
 
-    def put_block(blk, ci):
+    def put_block(bits, blk, ci):
         t = 0 if ci == 0 else 1
         zz = blk.reshape(64)[ZIGZAG]
         diff = int(zz[0]) - pred[ci]
@@ -183,20 +179,39 @@ def encode_baseline(rgb, sampling=((1, 2), (1, 1), (1, 1)), quality_scale=1.0, r
         if end < 63:
             bits.put(*ac_codes[t][0x00])
 
-    count, rst = 0, 0
-    for my in range(mcus_y):
-        for mx in range(mcus_x):
+    def write_scan(cis):
+        nonlocal pred
+        sos = bytes([len(cis)])
+        for ci in cis:
+            sos += bytes([ci + 1, 0x00 if ci == 0 else 0x11])
+        seg(0xDA, sos + bytes([0, 63, 0]))
+        bits = _Bits()
+        pred = [0] * len(comps)
+        if len(cis) == 1 and len(comps) > 1:  # the component's own grid: ceil(samples / 8) blocks each way, one block per MCU
+            ci = cis[0]
+            H, V = sampling[ci]
+            bw = -(-(-(-w * H // hmax)) // 8)
+            bh = -(-(-(-h * V // vmax)) // 8)
+            units = [[(ci, by, bx)] for by in range(bh) for bx in range(bw)]
+        else:
+            units = [[(ci, my * sampling[ci][1] + v, mx * sampling[ci][0] + hh) for ci in cis for v in range(sampling[ci][1]) for hh in range(sampling[ci][0])]
+                     for my in range(mcus_y) for mx in range(mcus_x)]
+        rst = 0
+        for count, unit in enumerate(units):
             if restart_interval and count and count % restart_interval == 0:
                 bits.flush()
                 bits.out.extend(bytes([0xFF, 0xD0 + (rst & 7)]))
                 rst += 1
                 pred = [0] * len(comps)
-            for ci, (H, V) in enumerate(sampling):
-                for v in range(V):
-                    for hh in range(H):
-                        put_block(blocks[ci][my * V + v, mx * H + hh], ci)
-            count += 1
-    bits.flush()
-    out.extend(bits.out)
+            for ci, by, bx in unit:
+                put_block(bits, blocks[ci][by, bx], ci)
+        bits.flush()
+        out.extend(bits.out)
+
+    if interleaved or len(comps) == 1:
+        write_scan(list(range(len(comps))))
+    else:
+        for ci in range(len(comps)):
+            write_scan([ci])
     out.extend(b"\xff\xd9")
     return bytes(out)

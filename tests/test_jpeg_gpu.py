@@ -73,9 +73,12 @@ def test_generated_streams_decode_like_the_oracle(eng, oracle):
             assert np.array_equal(eng.jpeg_decode(data, flavour), oracle.jpeg_decode(data, flavour)), ((w, h), samp, flavour)
 
 
+@pytest.mark.parametrize("entropy", [0, 1])
 @pytest.mark.parametrize("flavour", [0, 1])
-def test_hash_batch_of_mixed_files_matches_decode_then_hash_on_the_cpu(eng, oracle, flavour):
-    """files of many geometries, gray and colour, below 5 px, above 512 px, 512x512 (fused kernel), undecodable: one call"""
+def test_hash_batch_of_mixed_files_matches_decode_then_hash_on_the_cpu(eng, oracle, flavour, entropy):
+    """files of many geometries, gray and colour, below 5 px, above 512 px, 512x512 (fused kernel), undecodable: one call.
+    entropy = 1: the Huffman streams of the sequential files are walked on the device (one file per lane), the progressive ones by the host"""
+    eng.jpeg_set_entropy(entropy)
     files = [_read(n) for n in FILES]
     synth = oracle.synth_images(998, 4)  # 512x512 RGB, one near-duplicate pair
     from PIL import Image
@@ -89,9 +92,18 @@ def test_hash_batch_of_mixed_files_matches_decode_then_hash_on_the_cpu(eng, orac
         if mode == "RGB":
             kw["subsampling"] = ss
         files.append(ju.pillow_jpeg(ju.make_image(w, h, mode, seed=i), **kw))
+    # restart intervals, one scan per component, 4:4:0, optimised tables, 16-bit tables: the device walk's special cases
+    for i, (w, h, samp, rst, il) in enumerate([(97, 61, ((2, 2), (1, 1), (1, 1)), 3, True), (97, 61, ((2, 1), (1, 1), (1, 1)), 1, False),
+                                              (64, 200, ((1, 2), (1, 1), (1, 1)), 0, False), (40, 40, ((1, 1), (1, 1), (1, 1)), 7, False)]):
+        files.append(ju.encode_baseline(np.array(ju.make_image(w, h, seed=20 + i)), samp, 0.5 + i, rst, sixteen_bit_tables=(i == 3), interleaved=il))
+    files.append(ju.pillow_jpeg(ju.make_image(200, 120, seed=31), quality=97, optimize=True, subsampling=2))
+    files.append(ju.pillow_jpeg(ju.make_image(160, 90, seed=32), quality=60, restart_marker_blocks=2))
     files.insert(5, b"\xff\xd8 this is not a JPEG")
     files.append(ju.pillow_jpeg(ju.make_image(16, 16).convert("CMYK")))
+    good = ju.pillow_jpeg(ju.make_image(80, 60, seed=33), quality=80)
+    files.append(good[: len(good) * 2 // 3])  # truncated entropy segment: zeros are fed behind the end, on the host and on the device
     out = eng.jpeg_pdq_hash_batch(files, flavour=flavour, threads=4, want_quality=True, want_coeffs=True, want_dihedral=True)
+    eng.jpeg_set_entropy(2)
     for i, data in enumerate(files):
         try:
             px = oracle.jpeg_decode(data, flavour)
@@ -108,6 +120,27 @@ def test_hash_batch_of_mixed_files_matches_decode_then_hash_on_the_cpu(eng, orac
             assert np.array_equal(out["dihedral"][i], oracle.dihedral_hashes(c)), i
     # the near-duplicate pair of the synthetic stripe survives JPEG coding as near duplicates
     assert oracle.hamming256(out["hash"][3], out["hash"][4]) <= 40  # files 3 and 4 are images 998 and 999 of the synthetic set
+
+
+def test_device_entropy_on_a_few_thousand_files_equals_host_entropy(eng, oracle):
+    """the automatic mode takes the device walk from 2048 sequential files: 3000 files (24 distinct, three geometries, progressive ones
+    mixed in) give byte for byte what the host threads give, and the oracle's hashes"""
+    from PIL import Image
+
+    synth = oracle.synth_images(100, 16)
+    base = [ju.pillow_jpeg(Image.fromarray(synth[k]), quality=75 + k, subsampling=2 * (k % 2), progressive=(k % 8 == 7)) for k in range(16)]
+    base += [ju.pillow_jpeg(ju.make_image(200 + 8 * k, 120, seed=k), quality=85, restart_marker_blocks=(4 if k % 2 else 0)) for k in range(4)]
+    base += [ju.encode_baseline(np.array(ju.make_image(64, 64, seed=40 + k)), ((1, 2), (1, 1), (1, 1)), 1.0, k, interleaved=bool(k % 2)) for k in range(4)]
+    files = [base[(k * 7) % 24] for k in range(3000)]
+    eng.jpeg_set_entropy(0)
+    host = eng.jpeg_pdq_hash_batch(files, threads=16)
+    eng.jpeg_set_entropy(2)
+    auto = eng.jpeg_pdq_hash_batch(files, threads=16)
+    assert host["valid"].all() and auto["valid"].all() and not auto["status"].any()
+    assert np.array_equal(host["hash"], auto["hash"]) and np.array_equal(host["quality"].view(np.uint32), auto["quality"].view(np.uint32))
+    for k in range(24):
+        ok, h, q, _ = _oracle_hash(oracle, oracle.jpeg_decode(base[(k * 7) % 24], 0))
+        assert ok and np.array_equal(auto["hash"][k], h)
 
 
 def test_hash_batch_larger_than_one_chunk_and_thread_counts_agree(eng, oracle):
