@@ -637,12 +637,14 @@ const uint8_t *destuff(const uint8_t *p, const uint8_t *end, uint8_t *&out, uint
 }
 }  // namespace
 
-int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used)
+int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used, InternTable intern, void *store)
 {
     if (!f.have_sof || f.progressive) return RPH_ERR_UNSUPPORTED;
     plan = StreamPlan();
     TableSpec dc[4], ac[4];
     bool dc_present[4] = {false, false, false, false}, ac_present[4] = {false, false, false, false};
+    uint32_t dc_id[4], ac_id[4];  // interned lazily, when a scan uses the table
+    bool dc_known[4] = {false, false, false, false}, ac_known[4] = {false, false, false, false};
     for (int i = 0; i < 4; i++) f.qt_present[i] = false;
     f.restart_interval = 0;
     f.adobe_transform = -1;
@@ -685,6 +687,7 @@ int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, 
                 memcpy(t.symbols, p + 17, (size_t)total);
                 t.total = (uint16_t)total;
                 (tc ? ac_present : dc_present)[th] = true;
+                (tc ? ac_known : dc_known)[th] = false;
                 p += 17 + total;
                 left -= 17 + total;
             }
@@ -713,8 +716,17 @@ int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, 
                 sc.ci[i] = (uint8_t)c;
                 const int td = p[2 + 2 * i] >> 4, ta = p[2 + 2 * i] & 15;
                 if (td > 3 || ta > 3 || !dc_present[td] || !ac_present[ta]) return RPH_ERR_INVALID_ARG;
-                sc.dc[i] = dc[td];
-                sc.ac[i] = ac[ta];
+                if (!dc_known[td]) {
+                    dc_id[td] = intern(store, dc[td]);
+                    dc_known[td] = true;
+                }
+                if (!ac_known[ta]) {
+                    ac_id[ta] = intern(store, ac[ta]);
+                    ac_known[ta] = true;
+                }
+                if (dc_id[td] == UINT32_MAX || ac_id[ta] == UINT32_MAX) return RPH_ERR_INVALID_ARG;
+                sc.dc[i] = dc_id[td];
+                sc.ac[i] = ac_id[ta];
             }
             sc.restart_interval = f.restart_interval;
             sc.stream_off = (uint32_t)(o - out);

@@ -61,18 +61,20 @@ struct ScanPlan {
     uint32_t stream_off = 0, stream_len = 0;  // de-stuffed entropy bytes of the scan in the job's stream buffer
     uint32_t restart_interval = 0;            // as defined when the scan starts
     uint8_t ns = 0, ci[3] = {0, 0, 0};
-    TableSpec dc[3], ac[3];                   // per component of the scan, as defined when the scan starts
+    uint32_t dc[3] = {0, 0, 0}, ac[3] = {0, 0, 0};  // table ids (from the caller's interning function) per component of the scan
 };
 struct StreamPlan {
     int n_scans = 0;
     ScanPlan scan[4];
 };
+// Gives a table an id; equal tables get equal ids (the device keeps one lookup table per id).  UINT32_MAX = not a valid Huffman table.
+typedef uint32_t (*InternTable)(void *store, const TableSpec &t);
 
 // Sequential (SOF0 / SOF1) files only.  Walks the markers of a file whose frame `f` came from parse_frame, copies the entropy-coded
 // bytes of each scan to `out` with the byte stuffing undone (0xFF00 -> 0xFF) and the RSTn markers dropped (the decoder byte-aligns
 // every restart_interval MCUs instead), 16 zero bytes after each scan; at most `cap` bytes (len + 64 always suffices).
 // RPH_ERR_UNSUPPORTED: progressive, or more than 4 scans -- the caller uses decode_coefficients for that file.
-int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used);
+int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used, InternTable intern, void *store);
 int build_device_lut(const TableSpec &t, DeviceLut &out);
 
 }  // namespace rphj

@@ -18,7 +18,11 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "jpeg_host.h"
@@ -40,7 +44,7 @@ struct JImage {
     uint32_t hs, vs;        // chroma upsampling factors (1 or 2)
     uint32_t pitch[3];
     uint32_t cw, ch;        // chroma samples the upsampler may use: real component samples (libjpeg) or the padded plane (zune)
-    uint32_t out_stride;    // bytes per output row: ncomp * align4(w)
+    uint32_t out_stride;    // bytes per output row: ncomp * align8(w)
     uint32_t pad;
 };
 
@@ -199,51 +203,6 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t *__restric
     }
 }
 
-struct PlaneView {
-    const uint8_t *p;
-    int pitch, w, h;
-};
-__device__ __forceinline__ int at(const PlaneView &pl, int x, int y)
-{
-    y = y < 0 ? 0 : (y >= pl.h ? pl.h - 1 : y);  // the edge row repeats above and below (libjpeg: jdmainct.c context rows)
-    return pl.p[(size_t)y * pl.pitch + x];
-}
-// chroma sample of the full-resolution grid at (x, y)
-template <int FL>
-__device__ __forceinline__ int upsampled(const PlaneView &pl, int x, int y, int hs, int vs)
-{
-    if (hs == 1 && vs == 1) return at(pl, x, y);
-    const int n = pl.w;
-    if (FL == RPH_JPEG_LIBJPEG) {
-        if (hs == 2 && n <= 2) return at(pl, x >> 1, vs == 2 ? (y >> 1) : y);  // jdsample.c: fancy upsampling needs > 2 columns
-        if (hs == 2 && vs == 1) {                                                // h2v1_fancy_upsample
-            const int c = x >> 1, v = at(pl, c, y);
-            if ((x & 1) == 0) return c == 0 ? v : (3 * v + at(pl, c - 1, y) + 1) >> 2;
-            return c == n - 1 ? v : (3 * v + at(pl, c + 1, y) + 2) >> 2;
-        }
-        if (hs == 1) {  // h1v2_fancy_upsample
-            const int r = y >> 1, lower = y & 1;
-            return (3 * at(pl, x, r) + at(pl, x, lower ? r + 1 : r - 1) + (lower ? 2 : 1)) >> 2;
-        }
-        // h2v2_fancy_upsample
-        const int r = y >> 1, rr = (y & 1) ? r + 1 : r - 1, c = x >> 1;
-        const int cs = 3 * at(pl, c, r) + at(pl, c, rr);
-        if ((x & 1) == 0) {
-            if (c == 0) return (cs * 4 + 8) >> 4;
-            return (3 * cs + (3 * at(pl, c - 1, r) + at(pl, c - 1, rr)) + 8) >> 4;
-        }
-        if (c == n - 1) return (cs * 4 + 7) >> 4;
-        return (3 * cs + (3 * at(pl, c + 1, r) + at(pl, c + 1, rr)) + 7) >> 4;
-    }
-    // zune-jpeg (recalled): vertical (3 a + b + 2) >> 2, then the same horizontally on the result; edge samples are copied
-    const int r = vs == 2 ? (y >> 1) : y, c = hs == 2 ? (x >> 1) : x;
-    const int rr = vs == 2 ? ((y & 1) ? r + 1 : r - 1) : r;
-    auto zv = [&](int cc) { return vs == 2 ? ((3 * at(pl, cc, r) + at(pl, cc, rr) + 2) >> 2) : at(pl, cc, r); };
-    const int v = zv(c);
-    if (hs == 1) return v;
-    if ((x & 1) == 0) return c == 0 ? v : (3 * v + zv(c - 1) + 2) >> 2;
-    return c == n - 1 ? v : (3 * v + zv(c + 1) + 2) >> 2;
-}
 template <int FL>
 __device__ __forceinline__ void ycc_to_rgb(int y, int cb, int cr, int &r, int &g, int &b)
 {
@@ -260,37 +219,111 @@ __device__ __forceinline__ void ycc_to_rgb(int y, int cb, int cr, int &r, int &g
     }
 }
 
-// grid: x = groups of 256 lanes over ceil(w / 4) * h four-pixel groups, y = image
+__device__ __forceinline__ void bytes4(uint32_t u, int *d)
+{
+    d[0] = (int)(u & 255u), d[1] = (int)((u >> 8) & 255u), d[2] = (int)((u >> 16) & 255u), d[3] = (int)(u >> 24);
+}
+
+// The 8 chroma samples of the full-resolution grid at (x0 .. x0 + 7, y) of one chroma plane (x0 a multiple of 8).  The plane is read
+// as aligned words -- the samples of the current and of the neighbouring chroma row under these 8 pixels plus one sample either side
+// -- instead of a byte gather per pixel and neighbour (the first form of this kernel was bound by exactly those gathers).
+//   libjpeg-turbo (jdsample.c): h2v1 / h2v2 / h1v2 "fancy" triangle filters; columns are replicated instead when the plane has <= 2 of them
+//   zune-jpeg (recalled): (3 a + b + 2) >> 2 vertically, then the same horizontally on the result; the first and last column are copied
+template <int FL>
+__device__ __forceinline__ void chroma8(const uint8_t *__restrict__ plane, int pitch, int n, int rows, int x0, int y, int hs, int vs, int (&out)[8])
+{
+    int r = vs == 2 ? (y >> 1) : y, rr = vs == 2 ? ((y & 1) ? r + 1 : r - 1) : r;
+    r = r >= rows ? rows - 1 : r;  // (only rows of the padding, beyond the image, can exceed the plane's samples)
+    rr = rr < 0 ? 0 : (rr >= rows ? rows - 1 : rr);  // the edge row repeats above and below (jdmainct.c context rows)
+    const uint8_t *pr = plane + (size_t)r * pitch, *prr = plane + (size_t)rr * pitch;
+    const bool lower = (y & 1) != 0;
+    if (hs == 1) {  // chroma at full horizontal resolution: 8 samples of the row (pair)
+        int a[8], b[8];
+        const uint2 ua = *reinterpret_cast<const uint2 *>(pr + x0), ub = *reinterpret_cast<const uint2 *>(prr + x0);
+        bytes4(ua.x, a), bytes4(ua.y, a + 4), bytes4(ub.x, b), bytes4(ub.y, b + 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (vs == 1)
+                out[i] = a[i];
+            else if (FL == RPH_JPEG_LIBJPEG)
+                out[i] = (3 * a[i] + b[i] + (lower ? 2 : 1)) >> 2;  // h1v2_fancy_upsample
+            else
+                out[i] = (3 * a[i] + b[i] + 2) >> 2;
+        }
+        return;
+    }
+    // hs == 2: chroma columns c0 - 1 .. c0 + 4 under pixels x0 .. x0 + 7
+    const int c0 = x0 >> 1;
+    int a[6], b[6];
+    bytes4(*reinterpret_cast<const uint32_t *>(pr + c0), a + 1);
+    bytes4(*reinterpret_cast<const uint32_t *>(prr + c0), b + 1);
+    const int cl = c0 > 0 ? c0 - 1 : 0, cr = c0 + 4 < pitch ? c0 + 4 : pitch - 1;
+    a[0] = pr[cl], a[5] = pr[cr], b[0] = prr[cl], b[5] = prr[cr];
+    if (FL == RPH_JPEG_LIBJPEG && n <= 2) {  // h2v1_upsample / h2v2_upsample: replication
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = a[1 + (i >> 1)];
+        return;
+    }
+    int v[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        if (vs == 1)
+            v[j] = a[j];
+        else if (FL == RPH_JPEG_LIBJPEG)
+            v[j] = 3 * a[j] + b[j];  // h2v2_fancy_upsample's column sums (scale 4)
+        else
+            v[j] = (3 * a[j] + b[j] + 2) >> 2;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int j = 1 + (i >> 1), c = c0 + (i >> 1);
+        const bool even = (i & 1) == 0;
+        const bool edge = even ? c == 0 : c == n - 1;
+        const int nb = even ? v[j - 1] : v[j + 1];
+        if (FL == RPH_JPEG_LIBJPEG) {
+            if (vs == 1)
+                out[i] = edge ? v[j] : (3 * v[j] + nb + (even ? 1 : 2)) >> 2;                    // h2v1_fancy_upsample
+            else
+                out[i] = edge ? (v[j] * 4 + (even ? 8 : 7)) >> 4 : (3 * v[j] + nb + (even ? 8 : 7)) >> 4;  // h2v2_fancy_upsample
+        } else {
+            out[i] = edge ? v[j] : (3 * v[j] + nb + 2) >> 2;
+        }
+    }
+}
+
+// grid: x = groups of 256 lanes over ceil(w / 8) * h eight-pixel groups, y = image.  Packed Rgb8 (Luma8 for one component) with
+// rows of ncomp * align8(w) bytes: what the PDQ kernels read.
 template <int FL>
 __global__ void __launch_bounds__(256) jpeg_color_kernel(const uint8_t *__restrict__ planes, const JImage *__restrict__ imgs, uint8_t *__restrict__ out)
 {
     const JImage im = imgs[blockIdx.y];
-    const uint32_t w4 = (im.w + 3) / 4;
+    const uint32_t w8 = (im.w + 7) / 8;
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= w4 * im.h) return;
-    const int y = (int)(t / w4), x0 = (int)(t % w4) * 4;
-    const uint8_t *yrow = planes + im.plane_off[0] + (size_t)y * im.pitch[0];
+    if (t >= w8 * im.h) return;
+    const int y = (int)(t / w8), x0 = (int)(t % w8) * 8;
+    const uint2 yy = *reinterpret_cast<const uint2 *>(planes + im.plane_off[0] + (size_t)y * im.pitch[0] + x0);  // planes are padded to whole blocks
     uint8_t *dst = out + im.out_off + (size_t)y * im.out_stride;
-    if (im.ncomp == 1) {  // Luma8: the plane's own bytes (the plane is padded to whole blocks, so 4 bytes are always there)
-        *reinterpret_cast<uint32_t *>(dst + x0) = (uint32_t)yrow[x0] | ((uint32_t)yrow[x0 + 1] << 8) | ((uint32_t)yrow[x0 + 2] << 16) | ((uint32_t)yrow[x0 + 3] << 24);
+    if (im.ncomp == 1) {
+        *reinterpret_cast<uint2 *>(dst + x0) = yy;
         return;
     }
-    PlaneView cbp{planes + im.plane_off[1], (int)im.pitch[1], (int)im.cw, (int)im.ch};
-    PlaneView crp{planes + im.plane_off[2], (int)im.pitch[2], (int)im.cw, (int)im.ch};
-    uint32_t px[12];
+    int ys[8], cb[8], cr[8];
+    bytes4(yy.x, ys), bytes4(yy.y, ys + 4);
+    chroma8<FL>(planes + im.plane_off[1], (int)im.pitch[1], (int)im.cw, (int)im.ch, x0, y, (int)im.hs, (int)im.vs, cb);
+    chroma8<FL>(planes + im.plane_off[2], (int)im.pitch[2], (int)im.cw, (int)im.ch, x0, y, (int)im.hs, (int)im.vs, cr);
+    uint32_t px[24];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int x = min(x0 + i, (int)im.w - 1);  // the tail of the last group repeats the last pixel into the row padding
+    for (int i = 0; i < 8; i++) {
         int r, g, b;
-        ycc_to_rgb<FL>(yrow[x], upsampled<FL>(cbp, x, y, (int)im.hs, (int)im.vs), upsampled<FL>(crp, x, y, (int)im.hs, (int)im.vs), r, g, b);
-        px[3 * i] = (uint32_t)r;
-        px[3 * i + 1] = (uint32_t)g;
-        px[3 * i + 2] = (uint32_t)b;
+        ycc_to_rgb<FL>(ys[i], cb[i], cr[i], r, g, b);
+        px[3 * i] = (uint32_t)r, px[3 * i + 1] = (uint32_t)g, px[3 * i + 2] = (uint32_t)b;
     }
-    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + 3 * x0);
-    d32[0] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-    d32[1] = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
-    d32[2] = px[8] | (px[9] << 8) | (px[10] << 16) | (px[11] << 24);
+    uint2 *d64 = reinterpret_cast<uint2 *>(dst + 3 * x0);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const uint32_t *p = px + 8 * q;
+        d64[q] = make_uint2(p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24), p[4] | (p[5] << 8) | (p[6] << 16) | (p[7] << 24));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -597,10 +630,37 @@ struct JpegPipe {
 };
 
 constexpr size_t CHUNK_COEF_BYTES = (size_t)192 << 20;   // host entropy, per slot: ~250 images of 512x512 4:2:0
-constexpr size_t SUB_COEF_BYTES = (size_t)1 << 30;        // device entropy: reconstruction sub-batch (~1300 such images)
+constexpr size_t SUB_COEF_BYTES = (size_t)4 << 30;        // device entropy: reconstruction sub-batch (~5400 such images)
 constexpr size_t MAX_IMAGE_COEF_BYTES = (size_t)3 << 30;  // one image beyond this is refused (RPH_ERR_UNSUPPORTED)
 constexpr uint32_t CHUNK_MAX_IMAGES = 4096;               // host entropy
 constexpr uint32_t DEVICE_ENTROPY_MIN_FILES = 2048;       // automatic mode: below this the host decodes (latency)
+
+// Huffman tables of a chunk, one per distinct content (most files of a collection share the four Annex K tables)
+struct TableStore {
+    std::mutex mu;
+    std::vector<rphj::DeviceLut> luts;
+    std::vector<rphj::TableSpec> specs;
+    std::unordered_multimap<uint64_t, uint32_t> by_hash;
+    static uint32_t intern(void *self, const rphj::TableSpec &t)
+    {
+        TableStore &T = *static_cast<TableStore *>(self);
+        uint64_t h = 1469598103934665603ULL;
+        for (int q = 1; q <= 16; q++) h = (h ^ t.counts[q]) * 1099511628211ULL;
+        for (int q = 0; q < t.total; q++) h = (h ^ t.symbols[q]) * 1099511628211ULL;
+        std::lock_guard<std::mutex> lock(T.mu);
+        auto range = T.by_hash.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it) {
+            const rphj::TableSpec &o = T.specs[it->second];
+            if (o.total == t.total && memcmp(o.counts + 1, t.counts + 1, 16) == 0 && memcmp(o.symbols, t.symbols, t.total) == 0) return it->second;
+        }
+        rphj::DeviceLut L;
+        if (rphj::build_device_lut(t, L) != RPH_OK) return UINT32_MAX;
+        T.luts.push_back(L);
+        T.specs.push_back(t);
+        T.by_hash.emplace(h, (uint32_t)T.luts.size() - 1);
+        return (uint32_t)T.luts.size() - 1;
+    }
+};
 
 struct Job {
     const uint8_t *data = nullptr;
@@ -614,8 +674,15 @@ struct Job {
 
 size_t out_bytes_of(const rphj::Frame &f)
 {
-    const size_t stride = (size_t)f.ncomp * align_up(f.w, 4);
+    const size_t stride = (size_t)f.ncomp * align_up(f.w, 8);
     return align_up(stride * f.h, 64);
+}
+
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline bool trace_on()
+{
+    static const bool on = getenv("RPH_JPEG_TRACE") != nullptr;
+    return on;
 }
 
 template <class F>
@@ -718,7 +785,7 @@ int build_descriptors(std::vector<Job> &jobs, const std::vector<uint32_t> &idx, 
             im.cw = flavour == RPH_JPEG_LIBJPEG ? f.comp[1].samp_w : f.comp[1].blocks_w * 8;
             im.ch = flavour == RPH_JPEG_LIBJPEG ? f.comp[1].samp_h : f.comp[1].blocks_h * 8;
         }
-        im.out_stride = (uint32_t)((size_t)f.ncomp * align_up(f.w, 4));
+        im.out_stride = (uint32_t)((size_t)f.ncomp * align_up(f.w, 8));
         im.out_off = out_bytes;
         out_bytes += out_bytes_of(f);
         D.image_of[r] = D.n_images;
@@ -741,7 +808,7 @@ int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, std::vector<
         i0 = std::min(i0, D.image_of[r]);
         i1 = std::max(i1, D.image_of[r] + 1);
         for (int c = 0; c < f.ncomp; c++) max_blocks = std::max(max_blocks, f.comp[c].blocks_w * f.comp[c].blocks_h);
-        max_groups = std::max<uint32_t>(max_groups, (uint32_t)(((f.w + 3) / 4) * (size_t)f.h));
+        max_groups = std::max<uint32_t>(max_groups, (uint32_t)(((f.w + 7) / 8) * (size_t)f.h));
     }
     if (i0 == UINT32_MAX) return RPH_OK;
     const JPlane *dp = reinterpret_cast<const JPlane *>(S.meta.d + D.off_planes) + p0;
@@ -768,7 +835,7 @@ int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, std::vector<
         const rphj::Frame &f = jobs[idx[first + r]].frame;
         size_t e = r + 1;
         while (e < r1 && D.image_of[e] != UINT32_MAX && jobs[idx[first + e]].frame.w == f.w && jobs[idx[first + e]].frame.h == f.h && jobs[idx[first + e]].frame.ncomp == f.ncomp) e++;
-        RPH_TRY(rph_pdq_hash_batch_dev(ctx, P.d_out[b] + hi[D.image_of[r]].out_off, (uint32_t)(e - r), f.w, f.h, (uint32_t)f.ncomp, (size_t)f.ncomp * align_up(f.w, 4), out_bytes_of(f),
+        RPH_TRY(rph_pdq_hash_batch_dev(ctx, P.d_out[b] + hi[D.image_of[r]].out_off, (uint32_t)(e - r), f.w, f.h, (uint32_t)f.ncomp, (size_t)f.ncomp * align_up(f.w, 8), out_bytes_of(f),
                                        R.hash + r * 32, out.quality ? R.quality + r * 4 : nullptr, out.coeffs ? R.coeffs + r * 1024 : nullptr,
                                        out.dihedral ? R.dihedral + r * 256 : nullptr, R.valid + r, s));
         r = e;
@@ -861,7 +928,7 @@ int run_host_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, const st
         if (out.want_hash) RPH_HIP_CHECK(hipMemcpyAsync(S.res.h, S.res.d, S.res_images * RES_BYTES, hipMemcpyDeviceToHost, s));
         if (out.pixels && m == 1 && jobs[idx[first]].status == RPH_OK) {  // single-image decode: rows without their padding
             const rphj::Frame &f = jobs[idx[first]].frame;
-            const size_t row = (size_t)f.ncomp * f.w, stride = (size_t)f.ncomp * align_up(f.w, 4);
+            const size_t row = (size_t)f.ncomp * f.w, stride = (size_t)f.ncomp * align_up(f.w, 8);
             RPH_HIP_CHECK(hipMemcpy2DAsync(out.pixels, row, P.d_out[b], stride, row, f.h, hipMemcpyDeviceToHost, s));
         }
         pend[b].active = true;
@@ -939,6 +1006,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
         RPH_TRY(S.reserve_res(m));
         RPH_TRY(S.stream_bytes.reserve(file_bytes + 64));
         // ---- streams and scan plans (host threads: memchr + memcpy)
+        const double t0 = now_ms();
         {
             size_t off = 0;
             uint64_t fb = 0;
@@ -950,42 +1018,14 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
                 fb += j.frame.total_blocks;
             }
         }
+        TableStore store;
+        std::vector<HImage> himgs(m);
         parallel_for(first, last, threads, [&](size_t i) {
             Job &j = jobs[idx[i]];
-            j.status = rphj::prepare_stream(j.data, j.len, j.frame, j.plan, S.stream_bytes.h + j.stream_off, align_up(j.len + 64, 16), &j.stream_used);
-        });
-        // files the walk does not take (more than four scans) go back to the host decoder; they keep their place in the chunk as holes
-        for (size_t i = first; i < last; i++) {
-            Job &j = jobs[idx[i]];
-            if (j.status == RPH_ERR_UNSUPPORTED || j.status == RPH_ERR_CAPACITY) leftover.push_back(idx[i]);
-        }
-        // ---- tables (de-duplicated by content), image records, lane order
-        std::vector<rphj::DeviceLut> luts;
-        std::vector<std::pair<uint64_t, uint32_t>> seen;  // (content hash, index): collisions are resolved by comparing the specs
-        std::vector<const rphj::TableSpec *> spec_of;
-        auto lut_of = [&](const rphj::TableSpec &t) -> uint32_t {
-            uint64_t hsh = 1469598103934665603ULL;
-            for (int q = 1; q <= 16; q++) hsh = (hsh ^ t.counts[q]) * 1099511628211ULL;
-            for (int q = 0; q < t.total; q++) hsh = (hsh ^ t.symbols[q]) * 1099511628211ULL;
-            for (auto &e : seen)
-                if (e.first == hsh && spec_of[e.second]->total == t.total && memcmp(spec_of[e.second]->counts, t.counts, 17) == 0 &&
-                    memcmp(spec_of[e.second]->symbols, t.symbols, t.total) == 0)
-                    return e.second;
-            rphj::DeviceLut L;
-            if (rphj::build_device_lut(t, L) != RPH_OK) return UINT32_MAX;
-            luts.push_back(L);
-            spec_of.push_back(&t);
-            seen.emplace_back(hsh, (uint32_t)luts.size() - 1);
-            return (uint32_t)luts.size() - 1;
-        };
-        std::vector<HImage> himgs(m);
-        std::vector<uint32_t> order;
-        order.reserve(m);
-        for (size_t r = 0; r < m; r++) {
-            Job &j = jobs[idx[first + r]];
-            HImage &hi = himgs[r];
+            HImage &hi = himgs[i - first];
             memset(&hi, 0, sizeof hi);
-            if (j.status != RPH_OK) continue;
+            j.status = rphj::prepare_stream(j.data, j.len, j.frame, j.plan, S.stream_bytes.h + j.stream_off, align_up(j.len + 64, 16), &j.stream_used, &TableStore::intern, &store);
+            if (j.status != RPH_OK) return;
             const rphj::Frame &f = j.frame;
             hi.first_block = j.first_block;
             hi.stream_base = j.stream_off;
@@ -997,8 +1037,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
                 const rphj::Comp &kc = f.comp[c];
                 hi.comp[c] = HComp{kc.blocks_w, kc.real_bw, kc.real_bh, (uint32_t)kc.first_block, kc.H, kc.V};
             }
-            bool ok = true;
-            for (int q = 0; q < j.plan.n_scans && ok; q++) {
+            for (int q = 0; q < j.plan.n_scans; q++) {
                 const rphj::ScanPlan &sp = j.plan.scan[q];
                 HScan &hs = hi.scan[q];
                 hs.off = sp.stream_off;
@@ -1007,17 +1046,21 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
                 hs.ns = sp.ns;
                 for (int c = 0; c < sp.ns; c++) {
                     hs.ci[c] = sp.ci[c];
-                    hs.dc[c] = lut_of(sp.dc[c]);
-                    hs.ac[c] = lut_of(sp.ac[c]);
-                    ok = ok && hs.dc[c] != UINT32_MAX && hs.ac[c] != UINT32_MAX;
+                    hs.dc[c] = sp.dc[c];
+                    hs.ac[c] = sp.ac[c];
                 }
             }
-            if (!ok) {
-                j.status = RPH_ERR_INVALID_ARG;
-                continue;
-            }
-            order.push_back((uint32_t)r);
+        });
+        const double t_prep = now_ms();
+        // files the walk does not take (more than four scans) go back to the host decoder; they keep their place in the chunk as holes
+        std::vector<uint32_t> order;
+        order.reserve(m);
+        for (size_t i = first; i < last; i++) {
+            Job &j = jobs[idx[i]];
+            if (j.status == RPH_ERR_UNSUPPORTED || j.status == RPH_ERR_CAPACITY) leftover.push_back(idx[i]);
+            if (j.status == RPH_OK) order.push_back((uint32_t)(i - first));
         }
+        const std::vector<rphj::DeviceLut> &luts = store.luts;
         // ---- meta buffer: reconstruction descriptors | HImage | order | tables
         const size_t recon_bytes = m * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128);
         const size_t off_himg = align_up(recon_bytes, 16), off_order = off_himg + m * sizeof(HImage), off_luts = align_up(off_order + m * 4, 16),
@@ -1030,20 +1073,37 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
         memcpy(S.meta.h + off_order, order.data(), order.size() * 4);
         if (!luts.empty()) memcpy(S.meta.h + off_luts, luts.data(), luts.size() * sizeof(rphj::DeviceLut));
         // ---- device: streams up, zeroed coefficients, the walk, then reconstruction + hashing sub-batch by sub-batch
+        const double t_desc = now_ms();
+        const bool tr = trace_on();  // RPH_JPEG_TRACE: synchronise after every phase and print where the time goes (stderr)
+        double t_up = 0, t_zero = 0, t_walk = 0, t_rec = 0;
+        auto lap = [&](double &t) {
+            if (tr) {
+                (void)hipStreamSynchronize(s);
+                t = now_ms();
+            }
+        };
         ResView R(S.res.d, S.res_images);
         RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
         if (!order.empty()) {
             RPH_HIP_CHECK(hipMemcpyAsync(S.stream_bytes.d, S.stream_bytes.h, file_bytes + 64, hipMemcpyHostToDevice, s));
             RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, meta_bytes, hipMemcpyHostToDevice, s));
+            lap(t_up);
             RPH_HIP_CHECK(hipMemsetAsync(P.d_coef, 0, blocks * 128, s));
+            lap(t_zero);
             hipLaunchKernelGGL(jpeg_huff_kernel, dim3(((uint32_t)order.size() + 63) / 64), dim3(64), 0, s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg),
                                reinterpret_cast<const uint32_t *>(S.meta.d + off_order), (uint32_t)order.size(), reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts),
                                P.d_coef, R.status);
             RPH_HIP_CHECK(hipGetLastError());
+            lap(t_walk);
             for (size_t q = 0; q < subs.size(); q++) {
                 const size_t r0 = subs[q], r1 = q + 1 < subs.size() ? subs[q + 1] : m;
                 RPH_TRY(reconstruct_and_hash(ctx, P, 0, S, jobs, idx, first, D, r0, r1, P.d_coef, flavour, out, s));
             }
+            lap(t_rec);
+            if (tr)
+                fprintf(stderr, "[rph_jpeg] chunk of %zu files (%.1f MB of entropy bytes, %.2f GB of coefficients, %zu tables, %zu sub-batches): prepare %.1f ms, "
+                                "descriptors %.1f ms, upload %.1f ms, zero %.1f ms, walk %.1f ms, reconstruct + hash %.1f ms\n",
+                        m, file_bytes / 1e6, blocks * 128 / 1e9, luts.size(), subs.size(), t_prep - t0, t_desc - t_prep, t_up - t_desc, t_zero - t_up, t_walk - t_zero, t_rec - t_walk);
         }
         RPH_HIP_CHECK(hipMemcpyAsync(S.res.h, S.res.d, S.res_images * RES_BYTES, hipMemcpyDeviceToHost, s));
         RPH_HIP_CHECK(hipEventRecord(S.done, s));

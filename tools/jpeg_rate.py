@@ -20,7 +20,8 @@ def main():
     ap.add_argument("--n", type=int, default=4000)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--distinct", type=int, default=64)
-    ap.add_argument("--threads", default="1,2,4,8,16,32")
+    ap.add_argument("--threads", default="1,4,16")
+    ap.add_argument("--device-n", type=int, default=100000, help="files per call for the device-entropy rows")
     a = ap.parse_args()
     from PIL import Image
 
@@ -48,13 +49,28 @@ def main():
             eng.jpeg_coefficients(f)
         dt = (time.perf_counter() - t) / len(base) / 2  # the wrapper decodes twice (size query + data)
         print(f"   host half alone (entropy decode), 1 thread:   {1 / dt:8.0f} files/s  ({dt * 1e3:.3f} ms)")
-        eng.jpeg_pdq_hash_batch(files[:256], threads=8)  # warm-up: staging buffers
+        eng.jpeg_set_entropy(0)
+        ref_hash = eng.jpeg_pdq_hash_batch(files[:256], threads=8)["hash"]  # warm-up: staging buffers
         for t_n in [int(x) for x in a.threads.split(",")]:
             t = time.perf_counter()
             out = eng.jpeg_pdq_hash_batch(files, threads=t_n, want_quality=True)
             dt = time.perf_counter() - t
             assert out["valid"].all()
-            print(f"   rph_jpeg_pdq_hash_batch threads={t_n:3d}: {a.n / dt:9.0f} files/s  {mb / dt:7.1f} MB/s of JPEG  {a.n * a.size * a.size * 3 / dt / 1e9:6.2f} GB/s of pixels")
+            print(f"   host entropy   threads={t_n:3d} n={a.n:6d}: {a.n / dt:9.0f} files/s  {mb / dt:7.1f} MB/s of JPEG  {a.n * a.size * a.size * 3 / dt / 1e9:6.2f} GB/s of pixels")
+        if kw.get("progressive"):
+            continue  # progressive files stay with the host decoder
+        eng.jpeg_set_entropy(1)
+        for n_dev in sorted({a.n, min(a.device_n, 20000), a.device_n}):
+            big = [base[k % a.distinct] for k in range(n_dev)]
+            for rep in range(2):
+                t = time.perf_counter()
+                out = eng.jpeg_pdq_hash_batch(big, threads=16, want_quality=True)
+                dt = time.perf_counter() - t
+                assert out["valid"].all()
+            assert np.array_equal(out["hash"][: a.distinct], ref_hash[: a.distinct])
+            bmb = sum(len(f) for f in big) / 1e6
+            print(f"   device entropy threads= 16 n={n_dev:6d}: {n_dev / dt:9.0f} files/s  {bmb / dt:7.1f} MB/s of JPEG  {n_dev * a.size * a.size * 3 / dt / 1e9:6.2f} GB/s of pixels")
+        eng.jpeg_set_entropy(0)
     eng.close()
 
 
