@@ -679,11 +679,21 @@ size_t out_bytes_of(const rphj::Frame &f)
 }
 
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-inline bool trace_on()
+inline int trace_level()  // RPH_JPEG_TRACE=1: synchronise after every device phase and print its time; 2: host-side timestamps only (no extra synchronisation)
 {
-    static const bool on = getenv("RPH_JPEG_TRACE") != nullptr;
-    return on;
+    static const int level = getenv("RPH_JPEG_TRACE") ? atoi(getenv("RPH_JPEG_TRACE")) : 0;
+    return level;
 }
+inline bool trace_on() { return trace_level() == 1; }
+#define RPH_JPEG_STAMP(...)                                   \
+    do {                                                      \
+        if (trace_level() == 2) {                             \
+            fprintf(stderr, "[rph_jpeg %9.1f ms] ", now_ms() - g_trace_t0); \
+            fprintf(stderr, __VA_ARGS__);                     \
+            fprintf(stderr, "\n");                            \
+        }                                                     \
+    } while (0)
+static double g_trace_t0 = 0;
 
 template <class F>
 void parallel_for(size_t first, size_t last, unsigned threads, F &&body)
@@ -843,6 +853,23 @@ int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, std::vector<
     return RPH_OK;
 }
 
+// The results of a chunk are fetched only when the chunk is known to be finished.  Enqueued behind the chunk's kernels instead, the
+// transfer would sit in the copy engine's queue waiting for them, and the next chunk's upload -- same engine, another stream --
+// would wait behind it (measured: uploads did not overlap the other lane's kernels at all).
+int fetch_results(Slot &S, size_t m, const Outputs &out, bool entropy_status)
+{
+    ResView H(S.res.h, S.res_images), D(S.res.d, S.res_images);
+    if (out.want_hash) {
+        RPH_HIP_CHECK(hipMemcpy(H.hash, D.hash, m * 32, hipMemcpyDeviceToHost));
+        if (out.quality) RPH_HIP_CHECK(hipMemcpy(H.quality, D.quality, m * 4, hipMemcpyDeviceToHost));
+        if (out.coeffs) RPH_HIP_CHECK(hipMemcpy(H.coeffs, D.coeffs, m * 1024, hipMemcpyDeviceToHost));
+        if (out.dihedral) RPH_HIP_CHECK(hipMemcpy(H.dihedral, D.dihedral, m * 256, hipMemcpyDeviceToHost));
+        RPH_HIP_CHECK(hipMemcpy(H.valid, D.valid, m, hipMemcpyDeviceToHost));
+    }
+    if (entropy_status) RPH_HIP_CHECK(hipMemcpy(H.status, D.status, m, hipMemcpyDeviceToHost));
+    return RPH_OK;
+}
+
 // results of a finished chunk -> the caller's arrays (scattered through idx)
 void scatter_results(const Slot &S, std::vector<Job> &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, const Outputs &out, bool entropy_status)
 {
@@ -870,6 +897,7 @@ int run_host_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, const st
     auto finish = [&](int b) -> int {
         if (!pend[b].active) return RPH_OK;
         RPH_HIP_CHECK(hipStreamSynchronize(P.slot[b].stream));
+        RPH_TRY(fetch_results(P.slot[b], pend[b].last - pend[b].first, out, false));
         scatter_results(P.slot[b], jobs, idx, pend[b].first, pend[b].last, out, false);
         pend[b].active = false;
         return RPH_OK;
@@ -925,7 +953,6 @@ int run_host_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, const st
             RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, D.off_end, hipMemcpyHostToDevice, s));
             RPH_TRY(reconstruct_and_hash(ctx, P, b, S, jobs, idx, first, D, 0, m, reinterpret_cast<const int16_t *>(S.coef.d), flavour, out, s));
         }
-        if (out.want_hash) RPH_HIP_CHECK(hipMemcpyAsync(S.res.h, S.res.d, S.res_images * RES_BYTES, hipMemcpyDeviceToHost, s));
         if (out.pixels && m == 1 && jobs[idx[first]].status == RPH_OK) {  // single-image decode: rows without their padding
             const rphj::Frame &f = jobs[idx[first]].frame;
             const size_t row = (size_t)f.ncomp * f.w, stride = (size_t)f.ncomp * align_up(f.w, 8);
@@ -953,7 +980,13 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
     size_t free_b = 0, total_b = 0;
     RPH_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     const size_t budget = std::max<size_t>((size_t)1 << 30, std::min<size_t>((free_b + P.d_coef_bytes) / 2, (size_t)96 << 30));
-    const size_t want = std::min(need, budget);
+    // Two lanes of resources (stream, staging, half of the coefficient buffer, reconstruction buffers), chunks alternate between
+    // them: the host prepares chunk k + 1 and its bytes cross PCIe while chunk k is on the device, and the latency-bound walk of one
+    // chunk runs beside the bandwidth-bound reconstruction of the other.  A call is cut into about four chunks when it is large
+    // enough for each to still fill the device's lanes (16 GB of coefficients = 20 000 images of 512x512); a smaller call is one chunk.
+    const size_t chunk_target = std::min(need, std::max(need / 4 + 128, (size_t)16 << 30));
+    const bool single = need <= chunk_target && need <= budget;
+    const size_t want = single ? need : std::min(budget, 2 * chunk_target);
     if (P.d_coef_bytes < want) {
         RPH_HIP_CHECK(hipDeviceSynchronize());
         if (P.d_coef) (void)hipFree(P.d_coef);
@@ -962,24 +995,31 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
         RPH_HIP_CHECK(hipMalloc((void **)&P.d_coef, want));
         P.d_coef_bytes = want;
     }
+    const size_t region = (single ? P.d_coef_bytes : P.d_coef_bytes / 2) / 128 * 128;
+    const size_t chunk_bytes = std::min(region, chunk_target);
     struct Pending {
         bool active = false;
         size_t first = 0, last = 0;
     } pend[2];
     auto finish = [&](int b) -> int {
         if (!pend[b].active) return RPH_OK;
-        RPH_HIP_CHECK(hipEventSynchronize(P.slot[b].done));  // every chunk runs on slot 0's stream (they share the coefficient buffer)
+        RPH_JPEG_STAMP("lane %d: waiting for its chunk", b);
+        RPH_HIP_CHECK(hipEventSynchronize(P.slot[b].done));
+        RPH_JPEG_STAMP("lane %d: chunk done", b);
+        RPH_TRY(fetch_results(P.slot[b], pend[b].last - pend[b].first, out, true));
         scatter_results(P.slot[b], jobs, idx, pend[b].first, pend[b].last, out, true);
+        RPH_JPEG_STAMP("lane %d: results scattered", b);
         pend[b].active = false;
         return RPH_OK;
     };
     RPH_TRY(P.slot[0].ready());
     RPH_TRY(P.slot[1].ready());
-    hipStream_t s = P.slot[0].stream;
     {
         size_t max_img = 0;  // a sub-batch holds at least one image
         for (uint32_t g : idx) max_img = std::max(max_img, (size_t)jobs[g].frame.total_blocks * 128);
-        RPH_TRY(P.reserve_recon(0, std::max(std::min(SUB_COEF_BYTES, std::max(want, (size_t)64 << 20)), max_img), s));
+        const size_t recon = std::max(std::min(SUB_COEF_BYTES, std::max(std::min(want, chunk_bytes), (size_t)64 << 20)), max_img);
+        RPH_TRY(P.reserve_recon(0, recon, P.slot[0].stream));
+        if (need > chunk_bytes) RPH_TRY(P.reserve_recon(1, recon, P.slot[1].stream));
     }
     const size_t n = idx.size();
     int k = 0;
@@ -988,20 +1028,22 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
         while (last < n) {
             const Job &j = jobs[idx[last]];
             const size_t nb = (size_t)j.frame.total_blocks;
-            if (last > first && (blocks + nb) * 128 > P.d_coef_bytes) break;
+            if (last > first && (blocks + nb) * 128 > chunk_bytes) break;
             blocks += nb;
             file_bytes += align_up(j.len + 64, 16);
             last++;
         }
-        if (blocks * 128 > P.d_coef_bytes) {  // one image larger than the whole buffer: the host path takes it
+        if (blocks * 128 > region) {  // one image larger than a whole region: the host path takes it
             leftover.push_back(idx[first]);
             first = last;
             k--;
             continue;
         }
         const int b = k & 1;
-        RPH_TRY(finish(b));  // the staging of this slot is free again once its chunk (two chunks back) is done
+        RPH_TRY(finish(b));  // the lane is free again once its previous chunk (two chunks back) has delivered its results
         Slot &S = P.slot[b];
+        hipStream_t s = S.stream;
+        int16_t *d_coef = P.d_coef + (single ? 0 : (size_t)b * (region / 2));
         const size_t m = last - first;
         RPH_TRY(S.reserve_res(m));
         RPH_TRY(S.stream_bytes.reserve(file_bytes + 64));
@@ -1052,6 +1094,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
             }
         });
         const double t_prep = now_ms();
+        RPH_JPEG_STAMP("lane %d: chunk %d prepared (%zu files)", b, k, m);
         // files the walk does not take (more than four scans) go back to the host decoder; they keep their place in the chunk as holes
         std::vector<uint32_t> order;
         order.reserve(m);
@@ -1068,7 +1111,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
         RPH_TRY(S.meta.reserve(meta_bytes));
         ChunkDesc D;
         std::vector<size_t> subs;
-        RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, P.recon_coef_bytes[0], S.meta.h, 0, D, subs));
+        RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, P.recon_coef_bytes[b], S.meta.h, 0, D, subs));
         memcpy(S.meta.h + off_himg, himgs.data(), m * sizeof(HImage));
         memcpy(S.meta.h + off_order, order.data(), order.size() * 4);
         if (!luts.empty()) memcpy(S.meta.h + off_luts, luts.data(), luts.size() * sizeof(rphj::DeviceLut));
@@ -1088,16 +1131,16 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
             RPH_HIP_CHECK(hipMemcpyAsync(S.stream_bytes.d, S.stream_bytes.h, file_bytes + 64, hipMemcpyHostToDevice, s));
             RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, meta_bytes, hipMemcpyHostToDevice, s));
             lap(t_up);
-            RPH_HIP_CHECK(hipMemsetAsync(P.d_coef, 0, blocks * 128, s));
+            RPH_HIP_CHECK(hipMemsetAsync(d_coef, 0, blocks * 128, s));
             lap(t_zero);
             hipLaunchKernelGGL(jpeg_huff_kernel, dim3(((uint32_t)order.size() + 63) / 64), dim3(64), 0, s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg),
                                reinterpret_cast<const uint32_t *>(S.meta.d + off_order), (uint32_t)order.size(), reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts),
-                               P.d_coef, R.status);
+                               d_coef, R.status);
             RPH_HIP_CHECK(hipGetLastError());
             lap(t_walk);
             for (size_t q = 0; q < subs.size(); q++) {
                 const size_t r0 = subs[q], r1 = q + 1 < subs.size() ? subs[q + 1] : m;
-                RPH_TRY(reconstruct_and_hash(ctx, P, 0, S, jobs, idx, first, D, r0, r1, P.d_coef, flavour, out, s));
+                RPH_TRY(reconstruct_and_hash(ctx, P, b, S, jobs, idx, first, D, r0, r1, d_coef, flavour, out, s));
             }
             lap(t_rec);
             if (tr)
@@ -1105,8 +1148,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
                                 "descriptors %.1f ms, upload %.1f ms, zero %.1f ms, walk %.1f ms, reconstruct + hash %.1f ms\n",
                         m, file_bytes / 1e6, blocks * 128 / 1e9, luts.size(), subs.size(), t_prep - t0, t_desc - t_prep, t_up - t_desc, t_zero - t_up, t_walk - t_zero, t_rec - t_walk);
         }
-        RPH_HIP_CHECK(hipMemcpyAsync(S.res.h, S.res.d, S.res_images * RES_BYTES, hipMemcpyDeviceToHost, s));
         RPH_HIP_CHECK(hipEventRecord(S.done, s));
+        RPH_JPEG_STAMP("lane %d: chunk %d enqueued", b, k);
         pend[b].active = true;
         pend[b].first = first;
         pend[b].last = last;
@@ -1132,7 +1175,10 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
     unsigned threads = n_threads ? n_threads : std::max(1u, std::thread::hardware_concurrency());
     threads = std::min(threads, 256u);
 
+    g_trace_t0 = now_ms();
+    RPH_JPEG_STAMP("call: %u files", n);
     std::vector<Job> jobs(n);
+    RPH_JPEG_STAMP("jobs allocated (%zu bytes each)", sizeof(Job));
     parallel_for(0, n, n >= 1024 ? threads : 1, [&](size_t i) {
         Job &j = jobs[i];
         j.data = data[i];
@@ -1140,6 +1186,7 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
         j.status = (j.data && j.len) ? rphj::parse_frame(j.data, j.len, j.frame) : RPH_ERR_INVALID_ARG;
         if (j.status == RPH_OK && j.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) j.status = RPH_ERR_UNSUPPORTED;
     });
+    RPH_JPEG_STAMP("frames parsed");
     // which files walk their Huffman streams on the device: sequential ones, when the batch is large enough to fill lanes
     std::vector<uint32_t> host_idx, dev_idx;
     for (uint32_t i = 0; i < n; i++) {
@@ -1161,6 +1208,7 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
         std::sort(host_idx.begin(), host_idx.end());
     }
     if (!host_idx.empty()) RPH_TRY(run_host_entropy(ctx, P, jobs, host_idx, flavour, threads, out));
+    RPH_JPEG_STAMP("all chunks done");
     int worst = RPH_OK;
     for (uint32_t i = 0; i < n; i++) {
         if (out.status) out.status[i] = jobs[i].status;
