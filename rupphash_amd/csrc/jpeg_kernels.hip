@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -366,11 +367,24 @@ __device__ __forceinline__ T sel3(uint32_t i, T a, T b, T c)
     return i == 0 ? a : (i == 1 ? b : c);
 }
 
+// LDS_TABLES > 0: the chunk has at most that many distinct Huffman tables (a photo collection usually has the four Annex K tables) and
+// every wave keeps a copy in LDS: the table lookup is on the critical path of every symbol, and an LDS read returns in a tenth of the
+// time of a cached global read.
+constexpr int HUFF_LDS_TABLES = 8;
+template <int LDS_TABLES>
 __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const uint32_t *__restrict__ order, uint32_t n,
-                                                       const rphj::DeviceLut *__restrict__ luts, int16_t *__restrict__ coef, uint8_t *__restrict__ status)
+                                                       const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts, int16_t *__restrict__ coef, uint8_t *__restrict__ status)
 {
     __shared__ uint8_t zz[80];
+    __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
     for (int t = threadIdx.x; t < 80; t += 64) zz[t] = c_zigzag[t];
+    if (LDS_TABLES > 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(g_luts);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_luts);
+        const uint32_t words = n_luts * (uint32_t)(sizeof(rphj::DeviceLut) / 16);
+        for (uint32_t t = threadIdx.x; t < words; t += 64) dst[t] = src[t];
+    }
+    const rphj::DeviceLut *luts = LDS_TABLES > 0 ? s_luts : g_luts;
     __syncthreads();
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
     if (slot >= n) return;
@@ -403,6 +417,14 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
         uint32_t off = 0;
         uint64_t acc = 0;
         int nb = 0;
+        // the next 4 bytes are always already on their way (loaded one refill ahead), so a refill never waits for memory
+        auto load_be32 = [&](uint32_t at) -> uint32_t {
+            const uint32_t o = at < slen + 8 ? at : slen + 8;  // 16 zero bytes lie behind the scan: the look-ahead is safe, and a corrupt stream reads zeros there for ever
+            const uintptr_t a = (uintptr_t)(sp + o);
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+            return __builtin_bswap32(__builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(a & 3)));
+        };
+        uint32_t ahead = load_be32(0);
         // position: component i of the MCU, block (h, v) of the component, MCU (mx, my); k = next coefficient index (zigzag order)
         uint32_t i = 0, h = 0, v = 0, mx = 0, my = 0, k = 0, until = ri;
         uint32_t Hc = H0, Vc = V0, BWc = BW0, FBc = FB0;
@@ -411,14 +433,11 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
         bool is_dc = true, done = MX == 0 || MY == 0;
         uint64_t base = (img_fb + FBc) * 64;
         for (uint64_t it = 0; !done && it < max_it; it++) {
-            if (nb < 32) {  // 4 more bytes (the 16 zero bytes behind the scan make the look-ahead safe; a corrupt stream reads zeros there for ever)
-                const uint32_t o = off < slen + 8 ? off : slen + 8;
-                const uintptr_t a = (uintptr_t)(sp + o);
-                const uint32_t *w = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
-                const uint32_t dw = __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(a & 3));
-                acc |= (uint64_t)__builtin_bswap32(dw) << (32 - nb);
+            if (nb < 32) {  // 4 more bytes
+                acc |= (uint64_t)ahead << (32 - nb);
                 nb += 32;
                 off += 4;
+                ahead = load_be32(off);
             }
             const rphj::DeviceLut *L = is_dc ? DCc : ACc;
             const uint32_t e = L->look[(uint32_t)(acc >> 54)];
@@ -672,6 +691,8 @@ struct Job {
     size_t stream_off = 0, stream_used = 0;
 };
 
+using Jobs = std::vector<Job>;
+
 size_t out_bytes_of(const rphj::Frame &f)
 {
     const size_t stride = (size_t)f.ncomp * align_up(f.w, 8);
@@ -738,7 +759,7 @@ struct ChunkDesc {
 };
 
 // Sub-batch boundaries are where the offsets of planes and pixels restart from 0: `sub_of[r]` = first chunk position of r's sub-batch.
-int build_descriptors(std::vector<Job> &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, int flavour, size_t sub_coef_bytes, uint8_t *h_meta, size_t meta_base,
+int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, int flavour, size_t sub_coef_bytes, uint8_t *h_meta, size_t meta_base,
                       ChunkDesc &D, std::vector<size_t> &sub_starts)
 {
     const size_t m = last - first;
@@ -805,7 +826,7 @@ int build_descriptors(std::vector<Job> &jobs, const std::vector<uint32_t> &idx, 
 }
 
 // IDCT + upsampling / colour + hashing of chunk positions [r0, r1) (one sub-batch: its planes and pixels fit the slot's reconstruction buffers)
-int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, std::vector<Job> &jobs, const std::vector<uint32_t> &idx, size_t first, const ChunkDesc &D, size_t r0,
+int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, Jobs &jobs, const std::vector<uint32_t> &idx, size_t first, const ChunkDesc &D, size_t r0,
                          size_t r1, const int16_t *d_coef, int flavour, const Outputs &out, hipStream_t s)
 {
     // the planes and images of the sub-batch are contiguous in the descriptor arrays
@@ -871,7 +892,7 @@ int fetch_results(Slot &S, size_t m, const Outputs &out, bool entropy_status)
 }
 
 // results of a finished chunk -> the caller's arrays (scattered through idx)
-void scatter_results(const Slot &S, std::vector<Job> &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, const Outputs &out, bool entropy_status)
+void scatter_results(const Slot &S, Jobs &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, const Outputs &out, bool entropy_status)
 {
     ResView R(S.res.h, S.res_images);
     for (size_t r = 0; r < last - first; r++) {
@@ -888,7 +909,7 @@ void scatter_results(const Slot &S, std::vector<Job> &jobs, const std::vector<ui
 }
 
 // ---- host entropy decoding: the files idx[...] in chunks over the two slots
-int run_host_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, const std::vector<uint32_t> &idx, int flavour, unsigned threads, const Outputs &out)
+int run_host_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, const std::vector<uint32_t> &idx, int flavour, unsigned threads, const Outputs &out)
 {
     struct Pending {
         bool active = false;
@@ -969,7 +990,7 @@ int run_host_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, const st
 }
 
 // ---- device entropy decoding: the sequential files idx[...]; files the device walk does not take come back in `leftover` for the host
-int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::vector<uint32_t> idx, int flavour, unsigned threads, const Outputs &out,
+int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32_t> idx, int flavour, unsigned threads, const Outputs &out,
                        std::vector<uint32_t> &leftover)
 {
     // images of similar stream length share a wave: sort the whole list by file length first (chunks then are slices of it)
@@ -984,7 +1005,10 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
     // them: the host prepares chunk k + 1 and its bytes cross PCIe while chunk k is on the device, and the latency-bound walk of one
     // chunk runs beside the bandwidth-bound reconstruction of the other.  A call is cut into about four chunks when it is large
     // enough for each to still fill the device's lanes (16 GB of coefficients = 20 000 images of 512x512); a smaller call is one chunk.
-    const size_t chunk_target = std::min(need, std::max(need / 4 + 128, (size_t)16 << 30));
+    size_t min_chunk = (size_t)16 << 30, parts = 4;
+    if (const char *e = getenv("RPH_JPEG_CHUNK_GB")) min_chunk = (size_t)atoi(e) << 30;  // experiments
+    if (const char *e = getenv("RPH_JPEG_PARTS")) parts = (size_t)atoi(e);
+    const size_t chunk_target = std::min(need, std::max(need / parts + 128, min_chunk));
     const bool single = need <= chunk_target && need <= budget;
     const size_t want = single ? need : std::min(budget, 2 * chunk_target);
     if (P.d_coef_bytes < want) {
@@ -1133,9 +1157,18 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, std::vector<Job> &jobs, std::v
             lap(t_up);
             RPH_HIP_CHECK(hipMemsetAsync(d_coef, 0, blocks * 128, s));
             lap(t_zero);
-            hipLaunchKernelGGL(jpeg_huff_kernel, dim3(((uint32_t)order.size() + 63) / 64), dim3(64), 0, s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg),
-                               reinterpret_cast<const uint32_t *>(S.meta.d + off_order), (uint32_t)order.size(), reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts),
-                               d_coef, R.status);
+            {
+                const dim3 grid(((uint32_t)order.size() + 63) / 64);
+                const HImage *d_himg = reinterpret_cast<const HImage *>(S.meta.d + off_himg);
+                const uint32_t *d_order = reinterpret_cast<const uint32_t *>(S.meta.d + off_order);
+                const rphj::DeviceLut *d_luts = reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts);
+                if (luts.size() <= (size_t)HUFF_LDS_TABLES)
+                    hipLaunchKernelGGL(jpeg_huff_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, s, S.stream_bytes.d, d_himg, d_order, (uint32_t)order.size(), d_luts, (uint32_t)luts.size(),
+                                       d_coef, R.status);
+                else
+                    hipLaunchKernelGGL(jpeg_huff_kernel<0>, grid, dim3(64), 0, s, S.stream_bytes.d, d_himg, d_order, (uint32_t)order.size(), d_luts, (uint32_t)luts.size(), d_coef,
+                                       R.status);
+            }
             RPH_HIP_CHECK(hipGetLastError());
             lap(t_walk);
             for (size_t q = 0; q < subs.size(); q++) {
@@ -1177,8 +1210,7 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
 
     g_trace_t0 = now_ms();
     RPH_JPEG_STAMP("call: %u files", n);
-    std::vector<Job> jobs(n);
-    RPH_JPEG_STAMP("jobs allocated (%zu bytes each)", sizeof(Job));
+    Jobs jobs(n);  // (first-touching the storage from the parsing threads instead is 5x slower: page faults under contention)
     parallel_for(0, n, n >= 1024 ? threads : 1, [&](size_t i) {
         Job &j = jobs[i];
         j.data = data[i];
