@@ -84,6 +84,8 @@ def parse_args():
     ap.add_argument("--e2e-steps", type=int, default=3)
     ap.add_argument("--only", default="", help="comma list of phases to run: pdq, e2e, hamming (default: all)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget per cpu_baseline leg")
+    ap.add_argument("--jpeg-files", type=int, default=100_000, help="files per call of the JPEG leg (SURVEY 8f row N3; rank 0 at N = 1 only)")
+    ap.add_argument("--no-jpeg", action="store_true", help="skip the JPEG leg")
     return ap.parse_args()
 
 
@@ -101,9 +103,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    phases = set(p for p in args.only.split(",") if p) or {"pdq", "e2e", "hamming"}
+    phases = set(p for p in args.only.split(",") if p) or {"pdq", "e2e", "hamming", "jpeg"}
     if args.no_e2e:
         phases.discard("e2e")
+    if args.no_jpeg:
+        phases.discard("jpeg")
 
     # The CPU oracle (the checker and the cpu_baseline leg) is loaded BEFORE the GPU is initialised and is never built from
     # here: a `make` child of a process that holds the GPU (or runs under a profiler's preload) would be a forbidden exec.
@@ -423,6 +427,16 @@ def main():
     del imgs, img_sample_dev
     torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------------ JPEG files -> hashes (row N3; rank 0, N = 1)
+    if "jpeg" in phases and rank == 0 and world == 1:
+        try:
+            result["jpeg"] = jpeg_leg(eng, np, args, oracle)
+            if not result["jpeg"].get("valid", True):
+                valid = False
+                problems.append("jpeg: " + result["jpeg"].get("problem", "results differ"))
+        except ImportError as e:  # Pillow writes the test files
+            result["jpeg"] = {"skipped": str(e)}
+
     # ------------------------------------------------------------------ the reference's own published cases (rank 0, N = 1)
     if rank == 0 and world == 1 and not args.no_reference_cases:
         result["reference_cases"] = reference_cases(eng, np)
@@ -439,6 +453,71 @@ def main():
     eng.close()
     if not valid:
         sys.exit(1)
+
+
+def jpeg_leg(eng, np, args, oracle):
+    """Row N3: JPEG FILES in host memory -> PDQ hashes (load_image_fast + generate_pdq_features, scanner.rs:461-508, :1410), as one call.
+    Files: the first 64 images of the synthetic sequence, JPEG-coded by Pillow (baseline, 4:2:0, quality 85: what cameras write),
+    repeated to --jpeg-files.  Timed around the C call (the file pointer / length arrays are what a C caller already holds); PCIe is
+    inside the timed region by definition -- the files start in host memory."""
+    import io
+
+    from PIL import Image
+
+    distinct = 64
+    imgs = eng.synth_images(0, distinct)
+    base = []
+    for k in range(distinct):
+        buf = io.BytesIO()
+        Image.fromarray(imgs[k]).save(buf, "JPEG", quality=85, subsampling=2)
+        base.append(buf.getvalue())
+    n = args.jpeg_files
+    files = eng.jpeg_file_list([base[k % distinct] for k in range(n)])
+    file_bytes = sum(len(base[k % distinct]) for k in range(n))
+    out = {"files": n, "distinct_files": distinct, "file": "512x512 baseline JPEG, 4:2:0, quality 85 (Pillow / libjpeg-turbo encoder)",
+           "mean_file_bytes": file_bytes / n, "flavour": "zune (parity unpinned against zune-jpeg; the libjpeg flavour is pinned against libjpeg-turbo)"}
+    cores = cpu_inventory()["threads_used"]
+    # entropy decoding on the device: one file per lane
+    eng.jpeg_set_entropy(1)
+    eng.jpeg_pdq_hash_batch(files, threads=cores)  # buffers
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        dev = eng.jpeg_pdq_hash_batch(files, threads=cores)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["device_entropy"] = {"files_per_s": n / best, "seconds_per_call": best, "jpeg_MB_per_s": file_bytes / best / 1e6, "pixel_GB_per_s": n * IMG_BYTES / best / 1e9,
+                             "pcie_bytes_per_file": file_bytes / n, "host_threads": cores,
+                             "what": "host: frame headers + entropy bytes copied with the stuffing undone; device: Huffman walk (one file per lane), IDCT, upsampling, colour, PDQ"}
+    # entropy decoding on the host threads (what small batches and progressive files get)
+    eng.jpeg_set_entropy(0)
+    m = min(n, 8000)
+    sub = eng.jpeg_file_list([base[k % distinct] for k in range(m)])
+    eng.jpeg_pdq_hash_batch(sub, threads=cores)
+    t0 = time.perf_counter()
+    host = eng.jpeg_pdq_hash_batch(sub, threads=cores)
+    dt = time.perf_counter() - t0
+    eng.jpeg_set_entropy(2)
+    out["host_entropy"] = {"files_per_s": m / dt, "files": m, "host_threads": cores, "pcie_bytes_per_file": 6144 * 128,
+                           "what": "host threads: Huffman decoding to coefficients; device: IDCT, upsampling, colour, PDQ"}
+    ok = bool(dev["valid"].all() and host["valid"].all() and np.array_equal(dev["hash"][:m], host["hash"]))
+    # CPU: what one host thread does with the same files -- libjpeg-turbo through Pillow (SIMD; not the reference's zune-jpeg, which cannot
+    # be built here) for the decode, and the C oracle for decode + hash of the distinct files (the parity check)
+    t0 = time.perf_counter()
+    for f in base:
+        np.asarray(Image.open(io.BytesIO(f)))
+    dec = (time.perf_counter() - t0) / distinct
+    out["cpu_baseline"] = {"value": 1.0 / dec, "unit": "files/s (decode only)", "cores": 1, "kind": "third party: libjpeg-turbo via Pillow",
+                           "sample": f"{distinct} distinct files, one thread; the reference decodes with zune-jpeg 0.5.15 on every rayon worker"}
+    if oracle is not None:
+        for k in range(0, distinct, 8):
+            rc, coeffs, _ = oracle.pdq_features(oracle.jpeg_decode(base[k], 0))
+            ok = ok and rc == 0 and bool(np.array_equal(dev["hash"][k], oracle.to_hash(coeffs)))
+        out["gpu_hashes_equal_cpu_oracle_on_sample"] = ok
+    out["valid"] = ok
+    if not ok:
+        out["problem"] = "device-entropy, host-entropy and oracle hashes differ"
+    return out
 
 
 def reference_cases(eng, np):

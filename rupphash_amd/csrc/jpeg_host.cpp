@@ -731,10 +731,10 @@ int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, 
             sc.restart_interval = f.restart_interval;
             sc.stream_off = (uint32_t)(o - out);
             const uint8_t *stop = destuff(data + pos, data + len, o, o_end);
-            if (!stop || (size_t)(o_end - o) < 16) return RPH_ERR_CAPACITY;
+            if (!stop || (size_t)(o_end - o) < 32) return RPH_ERR_CAPACITY;
             sc.stream_len = (uint32_t)(o - out) - sc.stream_off;
-            memset(o, 0, 16);
-            o += 16;
+            memset(o, 0, 32);
+            o += 32;
             pos = (size_t)(stop - data);
             plan.n_scans++;
             break;

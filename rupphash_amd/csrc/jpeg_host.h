@@ -72,7 +72,7 @@ typedef uint32_t (*InternTable)(void *store, const TableSpec &t);
 
 // Sequential (SOF0 / SOF1) files only.  Walks the markers of a file whose frame `f` came from parse_frame, copies the entropy-coded
 // bytes of each scan to `out` with the byte stuffing undone (0xFF00 -> 0xFF) and the RSTn markers dropped (the decoder byte-aligns
-// every restart_interval MCUs instead), 16 zero bytes after each scan; at most `cap` bytes (len + 64 always suffices).
+// every restart_interval MCUs instead), 32 zero bytes after each scan; at most `cap` bytes (len + 160 always suffices).
 // RPH_ERR_UNSUPPORTED: progressive, or more than 4 scans -- the caller uses decode_coefficients for that file.
 int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used, InternTable intern, void *store);
 int build_device_lut(const TableSpec &t, DeviceLut &out);

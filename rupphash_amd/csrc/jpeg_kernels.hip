@@ -361,6 +361,10 @@ __constant__ uint8_t c_zigzag[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32,
                                      6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
                                      39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
 
+struct __attribute__((packed, aligned(4))) W2 {
+    uint32_t x, y;
+};
+
 template <class T>
 __device__ __forceinline__ T sel3(uint32_t i, T a, T b, T c)
 {
@@ -414,17 +418,20 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
         // bit reader: `off` bytes of the scan consumed into acc (MSB first), nb valid bits
         const uint8_t *sp = streams + im->stream_base + S->off;
         const uint32_t slen = S->len;
-        uint32_t off = 0;
-        uint64_t acc = 0;
-        int nb = 0;
-        // the next 4 bytes are always already on their way (loaded one refill ahead), so a refill never waits for memory
-        auto load_be32 = [&](uint32_t at) -> uint32_t {
-            const uint32_t o = at < slen + 8 ? at : slen + 8;  // 16 zero bytes lie behind the scan: the look-ahead is safe, and a corrupt stream reads zeros there for ever
-            const uintptr_t a = (uintptr_t)(sp + o);
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
-            return __builtin_bswap32(__builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(a & 3)));
+        // acc: the next bits, MSB first, nb of them valid.  Behind it two 8-byte words: q0 ready, q1 in flight (loaded one word ahead, so a
+        // refill never waits for memory), each fetched with ONE load instruction from a 4-byte-aligned address: the per-CU address unit,
+        // which takes a fully divergent wave access lane by lane, is what bounds this kernel, so loads per symbol are what matters.
+        const uint32_t lead = (uint32_t)((uintptr_t)sp & 3);
+        const uint8_t *sbase = sp - lead;
+        const uint32_t limit = ((slen + lead + 3) & ~3u) + 8;  // 32 zero bytes lie behind the scan: reading on is safe, and a corrupt stream reads zeros there for ever
+        auto load8 = [&](uint32_t at) -> uint64_t {
+            const W2 v = *reinterpret_cast<const W2 *>(sbase + (at < limit ? at : limit));
+            return ((uint64_t)__builtin_bswap32(v.x) << 32) | __builtin_bswap32(v.y);
         };
-        uint32_t ahead = load_be32(0);
+        uint64_t acc = (uint64_t)(__builtin_bswap32(*reinterpret_cast<const uint32_t *>(sbase)) << (8 * lead)) << 32;
+        int nb = 32 - 8 * (int)lead;
+        uint64_t q0 = load8(4), q1 = load8(12);
+        uint32_t q0n = 64, woff = 20;
         // position: component i of the MCU, block (h, v) of the component, MCU (mx, my); k = next coefficient index (zigzag order)
         uint32_t i = 0, h = 0, v = 0, mx = 0, my = 0, k = 0, until = ri;
         uint32_t Hc = H0, Vc = V0, BWc = BW0, FBc = FB0;
@@ -434,10 +441,16 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
         uint64_t base = (img_fb + FBc) * 64;
         for (uint64_t it = 0; !done && it < max_it; it++) {
             if (nb < 32) {  // 4 more bytes
-                acc |= (uint64_t)ahead << (32 - nb);
+                acc |= (q0 >> 32) << (32 - nb);
                 nb += 32;
-                off += 4;
-                ahead = load_be32(off);
+                q0 <<= 32;
+                q0n -= 32;
+                if (q0n == 0) {
+                    q0 = q1;
+                    q0n = 64;
+                    q1 = load8(woff);
+                    woff += 8;
+                }
             }
             const rphj::DeviceLut *L = is_dc ? DCc : ACc;
             const uint32_t e = L->look[(uint32_t)(acc >> 54)];
@@ -1054,7 +1067,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             const size_t nb = (size_t)j.frame.total_blocks;
             if (last > first && (blocks + nb) * 128 > chunk_bytes) break;
             blocks += nb;
-            file_bytes += align_up(j.len + 64, 16);
+            file_bytes += align_up(j.len + 160, 16);
             last++;
         }
         if (blocks * 128 > region) {  // one image larger than a whole region: the host path takes it
@@ -1079,7 +1092,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             for (size_t i = first; i < last; i++) {
                 Job &j = jobs[idx[i]];
                 j.stream_off = off;
-                off += align_up(j.len + 64, 16);
+                off += align_up(j.len + 160, 16);
                 j.first_block = fb;
                 fb += j.frame.total_blocks;
             }
@@ -1090,7 +1103,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             Job &j = jobs[idx[i]];
             HImage &hi = himgs[i - first];
             memset(&hi, 0, sizeof hi);
-            j.status = rphj::prepare_stream(j.data, j.len, j.frame, j.plan, S.stream_bytes.h + j.stream_off, align_up(j.len + 64, 16), &j.stream_used, &TableStore::intern, &store);
+            j.status = rphj::prepare_stream(j.data, j.len, j.frame, j.plan, S.stream_bytes.h + j.stream_off, align_up(j.len + 160, 16), &j.stream_used, &TableStore::intern, &store);
             if (j.status != RPH_OK) return;
             const rphj::Frame &f = j.frame;
             hi.first_block = j.first_block;

@@ -130,12 +130,17 @@ class Engine:
         check(self.L.rph_jpeg_decode(self.ctx, data, len(data), int(flavour), _ptr(out)), "rph_jpeg_decode")
         return out
 
-    def jpeg_pdq_hash_batch(self, files, flavour=0, threads=0, want_quality=True, want_coeffs=False, want_dihedral=False):
-        """files: list of JPEG byte strings (any mix of sizes).  Returns dict(hash, quality, coeffs, dihedral, valid, status):
-        valid[i] = 0 with status[i] != 0 for a file that cannot be decoded, valid[i] = 0 with status 0 for an image below 5 px."""
+    @staticmethod
+    def jpeg_file_list(files):
+        """The (pointer array, length array, n) a C caller would hold: build it once when the same files are hashed repeatedly"""
         n = len(files)
-        arr = (C.c_char_p * n)(*files)
-        lens = (C.c_size_t * n)(*[len(f) for f in files])
+        return (C.c_char_p * n)(*files), (C.c_size_t * n)(*[len(f) for f in files]), n
+
+    def jpeg_pdq_hash_batch(self, files, flavour=0, threads=0, want_quality=True, want_coeffs=False, want_dihedral=False):
+        """files: list of JPEG byte strings (any mix of sizes), or the tuple jpeg_file_list() made of one.  Returns dict(hash, quality,
+        coeffs, dihedral, valid, status): valid[i] = 0 with status[i] != 0 for a file that cannot be decoded, valid[i] = 0 with status 0
+        for an image below 5 px."""
+        arr, lens, n = files if isinstance(files, tuple) else self.jpeg_file_list(files)
         out = {
             "hash": np.zeros((n, 32), np.uint8),
             "quality": np.zeros(n, np.float32) if want_quality else None,

@@ -16,5 +16,9 @@ for path in sys.argv[1:]:
         h = d["hamming"]
         parts.append(f"hamming thr {h['threshold']} {h['value']:.0f} Gpairs/s frac {h['roofline']['frac']:.3f} ({h['roofline']['kernel_ms']:.2f} ms, "
                      f"PW {h['roofline']['prefix_dwords']}, edges {h['edges_found']}/{h['edges_expected']}, allgather {h['allgather_ms']:.2f} ms)")
+    if "jpeg" in d and "device_entropy" in d["jpeg"]:
+        j = d["jpeg"]
+        parts.append(f"jpeg {j['device_entropy']['files_per_s'] / 1e3:.0f} k files/s device entropy, {j['host_entropy']['files_per_s'] / 1e3:.1f} k host entropy, "
+                     f"libjpeg-turbo 1 thread {j['cpu_baseline']['value'] / 1e3:.2f} k")
     parts.append(f"valid={d.get('valid')}")
     print(" | ".join(parts))
