@@ -42,7 +42,7 @@ typedef enum rph_status {
     RPH_ERR_NO_DEVICE = -2,     /* no HIP device / not gfx950 */
     RPH_ERR_HIP = -3,           /* a HIP runtime call failed; rph_last_error() has the text */
     RPH_ERR_OOM = -4,
-    RPH_ERR_UNSUPPORTED = -5,   /* reserved */
+    RPH_ERR_UNSUPPORTED = -5,   /* an input this library does not take (e.g. a CMYK or arithmetic-coded JPEG): the caller keeps its own path for it */
     RPH_ERR_CAPACITY = -6       /* output capacity too small; the required count is still reported */
 } rph_status;
 
