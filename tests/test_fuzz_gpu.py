@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tool,seed", [("fuzz_hamming.py", 11), ("fuzz_grouping.py", 12), ("fuzz_pdq.py", 13)])
+@pytest.mark.parametrize("tool,seed", [("fuzz_hamming.py", 11), ("fuzz_grouping.py", 12), ("fuzz_pdq.py", 13), ("fuzz_jpeg.py", 14)])
 def test_differential_fuzz(tool, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(seed), "6"], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr[-2000:])
