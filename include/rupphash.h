@@ -343,7 +343,7 @@ int rph_jpeg_coefficients(const uint8_t *data, size_t len, uint32_t *geometry, u
 /* load_image_fast for one JPEG: pixels_out receives w * h * channels bytes, packed rows (Luma8 or Rgb8). */
 int rph_jpeg_decode(rph_ctx *ctx, const uint8_t *data, size_t len, int flavour, uint8_t *pixels_out);
 /* n files -> n hashes (optional quality / 256 coefficients / 8 dihedral hashes per file, as rph_pdq_hash_batch).
- * n_threads host threads undo the entropy coding (0 = all hardware threads).  valid_out[i] = 0 and status_out[i] != RPH_OK
+ * n_threads host threads undo the entropy coding (0 = as many as the process may use: affinity mask and cgroup CPU quota).  valid_out[i] = 0 and status_out[i] != RPH_OK
  * for a file that cannot be decoded (the call itself still returns RPH_OK); valid_out[i] = 0 with status RPH_OK for an
  * image below 5 px (generate_pdq_features' None, pdqhash.rs:167-169).  Files of any mix of sizes share a call. */
 int rph_jpeg_pdq_hash_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint32_t n, int flavour, uint32_t n_threads,
@@ -361,6 +361,9 @@ int rph_jpeg_pdq_hash_batch(rph_ctx *ctx, const uint8_t *const *data, const size
 #define RPH_JPEG_ENTROPY_DEVICE 1
 #define RPH_JPEG_ENTROPY_AUTO 2
 int rph_jpeg_set_entropy(rph_ctx *ctx, int where);
+/* The JPEG path keeps its staging and device buffers in the context between calls (for a large call up to half of the free device
+ * memory for the coefficients of the files in flight); this returns them.  The next call allocates again. */
+int rph_jpeg_release(rph_ctx *ctx);
 
 /* =====================================================================
  * 64-bit pHash bit operations (reference: src/phash.rs:137-255), host scalar

@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <sched.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -729,6 +731,30 @@ inline bool trace_on() { return trace_level() == 1; }
     } while (0)
 static double g_trace_t0 = 0;
 
+// Host threads when the caller does not say: what this process may actually use (its affinity mask, and the cgroup CPU quota a
+// container runs under -- hardware_concurrency() reports the machine's 256 threads inside a 16-CPU container)
+unsigned default_threads()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    long long quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "max 100000" or "1600000 100000"
+        char q[32] = "";
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(h, "%lld", &period) != 1) period = 100000;
+            fclose(h);
+        }
+    }
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    return n;
+}
+
 template <class F>
 void parallel_for(size_t first, size_t last, unsigned threads, F &&body)
 {
@@ -1218,7 +1244,7 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
     RPH_HIP_CHECK(hipSetDevice(ctx->device));
     if (!ctx->jpeg) ctx->jpeg = new JpegPipe();
     JpegPipe &P = *static_cast<JpegPipe *>(ctx->jpeg);
-    unsigned threads = n_threads ? n_threads : std::max(1u, std::thread::hardware_concurrency());
+    unsigned threads = n_threads ? n_threads : default_threads();
     threads = std::min(threads, 256u);
 
     g_trace_t0 = now_ms();
@@ -1330,6 +1356,18 @@ int rph_jpeg_coefficients(const uint8_t *data, size_t len, uint32_t *geometry, u
         memcpy(qt, f.qt, sizeof f.qt);
         return RPH_OK;
     });
+}
+
+int rph_jpeg_release(rph_ctx *ctx)
+{
+    if (!ctx) {
+        rph_set_error("rph_jpeg_release: null argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lock(ctx->jpeg_mu);
+    RPH_HIP_CHECK(hipSetDevice(ctx->device));
+    rph_jpeg_forget(ctx);
+    return RPH_OK;
 }
 
 int rph_jpeg_set_entropy(rph_ctx *ctx, int where)

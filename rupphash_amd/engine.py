@@ -123,6 +123,10 @@ class Engine:
         """0 = Huffman streams decoded by host threads, 1 = on the device (one file per lane), 2 = automatic (default)"""
         check(self.L.rph_jpeg_set_entropy(self.ctx, int(where)), "rph_jpeg_set_entropy")
 
+    def jpeg_release(self):
+        """give the JPEG path's cached staging / device buffers back"""
+        check(self.L.rph_jpeg_release(self.ctx), "rph_jpeg_release")
+
     def jpeg_decode(self, data, flavour=0):
         """load_image_fast for one JPEG byte string: (h, w) uint8 [Luma8] or (h, w, 3) [Rgb8], decoded on the device."""
         w, h, c = self.jpeg_info(data)

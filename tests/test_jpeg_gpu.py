@@ -162,6 +162,17 @@ def test_hash_batch_larger_than_one_chunk_and_thread_counts_agree(eng, oracle):
         assert np.array_equal(again["hash"], ref["hash"][:100])
 
 
+def test_default_threads_and_release(eng, oracle):
+    """n_threads = 0 (affinity mask / cgroup quota decide), and the cached buffers can be returned and come back on the next call"""
+    files = [ju.pillow_jpeg(ju.make_image(96 + k, 64, seed=k), quality=80) for k in range(40)]
+    a = eng.jpeg_pdq_hash_batch(files, threads=0)
+    eng.jpeg_release()
+    b = eng.jpeg_pdq_hash_batch(files, threads=2)
+    assert a["valid"].all() and np.array_equal(a["hash"], b["hash"])
+    ok, h, _, _ = _oracle_hash(oracle, oracle.jpeg_decode(files[7], 0))
+    assert ok and np.array_equal(a["hash"][7], h)
+
+
 def test_scanner_load_image_fast_mirror(eng, oracle):
     from rupphash_amd import scanner
 
