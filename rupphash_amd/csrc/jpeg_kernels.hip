@@ -47,8 +47,8 @@ struct JImage {
     uint32_t hs, vs;        // chroma upsampling factors (1 or 2)
     uint32_t pitch[3];
     uint32_t cw, ch;        // chroma samples the upsampler may use: real component samples (libjpeg) or the padded plane (zune)
-    uint32_t out_stride;    // bytes per output row: ncomp * align8(w)
-    uint32_t pad;
+    uint32_t out_stride;    // bytes per output row: channels * align8(w)
+    uint32_t luma_out;      // three components, but the hasher is the only reader: write Rec.601 luma (what to_luma601 makes of the RGB) instead of Rgb8
 };
 
 #define MUL(a, b) ((int32_t)((uint32_t)(a) * (uint32_t)(b)))
@@ -320,6 +320,13 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const uint8_t *__restri
         int r, g, b;
         ycc_to_rgb<FL>(ys[i], cb[i], cr[i], r, g, b);
         px[3 * i] = (uint32_t)r, px[3 * i + 1] = (uint32_t)g, px[3 * i + 2] = (uint32_t)b;
+    }
+    if (im.luma_out) {  // to_luma601 (pdqhash.rs:268-284) of the pixel just made: the Rgb8 image is never written nor read back
+        uint32_t l[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) l[i] = (299u * px[3 * i] + 587u * px[3 * i + 1] + 114u * px[3 * i + 2] + 500u) / 1000u;
+        *reinterpret_cast<uint2 *>(dst + x0) = make_uint2(l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24), l[4] | (l[5] << 8) | (l[6] << 16) | (l[7] << 24));
+        return;
     }
     uint2 *d64 = reinterpret_cast<uint2 *>(dst + 3 * x0);
 #pragma unroll
@@ -708,9 +715,14 @@ struct Job {
 
 using Jobs = std::vector<Job>;
 
-size_t out_bytes_of(const rphj::Frame &f)
+// Channels of the pixels the device writes for a file: Rgb8 only where someone reads RGB -- the caller (rph_jpeg_decode) or the fused
+// 512x512 RGB kernel; every other colour file is hashed from its Rec.601 luma, written directly (a third of the bytes, and the PDQ
+// paths start from luma anyway: Luma8 input is borrowed as it is, pdqhash.rs:176)
+inline uint32_t out_channels(const rphj::Frame &f, bool rgb_wanted) { return f.ncomp == 1 ? 1u : ((rgb_wanted || (f.w == 512 && f.h == 512)) ? 3u : 1u); }
+
+size_t out_bytes_of(const rphj::Frame &f, uint32_t channels)
 {
-    const size_t stride = (size_t)f.ncomp * align_up(f.w, 8);
+    const size_t stride = (size_t)channels * align_up(f.w, 8);
     return align_up(stride * f.h, 64);
 }
 
@@ -798,8 +810,8 @@ struct ChunkDesc {
 };
 
 // Sub-batch boundaries are where the offsets of planes and pixels restart from 0: `sub_of[r]` = first chunk position of r's sub-batch.
-int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, int flavour, size_t sub_coef_bytes, uint8_t *h_meta, size_t meta_base,
-                      ChunkDesc &D, std::vector<size_t> &sub_starts)
+int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, int flavour, bool rgb_wanted, size_t sub_coef_bytes, uint8_t *h_meta,
+                      size_t meta_base, ChunkDesc &D, std::vector<size_t> &sub_starts)
 {
     const size_t m = last - first;
     D.m = m;
@@ -855,9 +867,11 @@ int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first
             im.cw = flavour == RPH_JPEG_LIBJPEG ? f.comp[1].samp_w : f.comp[1].blocks_w * 8;
             im.ch = flavour == RPH_JPEG_LIBJPEG ? f.comp[1].samp_h : f.comp[1].blocks_h * 8;
         }
-        im.out_stride = (uint32_t)((size_t)f.ncomp * align_up(f.w, 8));
+        const uint32_t och = out_channels(f, rgb_wanted);
+        im.luma_out = f.ncomp == 3 && och == 1;
+        im.out_stride = (uint32_t)((size_t)och * align_up(f.w, 8));
         im.out_off = out_bytes;
-        out_bytes += out_bytes_of(f);
+        out_bytes += out_bytes_of(f, och);
         D.image_of[r] = D.n_images;
         hi[D.n_images++] = im;
     }
@@ -903,9 +917,10 @@ int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, Jobs &jobs, 
             continue;
         }
         const rphj::Frame &f = jobs[idx[first + r]].frame;
+        const uint32_t och = out_channels(f, out.pixels != nullptr);
         size_t e = r + 1;
         while (e < r1 && D.image_of[e] != UINT32_MAX && jobs[idx[first + e]].frame.w == f.w && jobs[idx[first + e]].frame.h == f.h && jobs[idx[first + e]].frame.ncomp == f.ncomp) e++;
-        RPH_TRY(rph_pdq_hash_batch_dev(ctx, P.d_out[b] + hi[D.image_of[r]].out_off, (uint32_t)(e - r), f.w, f.h, (uint32_t)f.ncomp, (size_t)f.ncomp * align_up(f.w, 8), out_bytes_of(f),
+        RPH_TRY(rph_pdq_hash_batch_dev(ctx, P.d_out[b] + hi[D.image_of[r]].out_off, (uint32_t)(e - r), f.w, f.h, och, (size_t)och * align_up(f.w, 8), out_bytes_of(f, och),
                                        R.hash + r * 32, out.quality ? R.quality + r * 4 : nullptr, out.coeffs ? R.coeffs + r * 1024 : nullptr,
                                        out.dihedral ? R.dihedral + r * 256 : nullptr, R.valid + r, s));
         r = e;
@@ -1005,7 +1020,7 @@ int run_host_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, const std::vector<ui
         });
         ChunkDesc D;
         std::vector<size_t> subs;
-        RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, SIZE_MAX / 256, S.meta.h, 0, D, subs));
+        RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, out.pixels != nullptr, SIZE_MAX / 256, S.meta.h, 0, D, subs));
         hipStream_t s = S.stream;
         RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
         if (D.n_images) {
@@ -1044,7 +1059,12 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     // them: the host prepares chunk k + 1 and its bytes cross PCIe while chunk k is on the device, and the latency-bound walk of one
     // chunk runs beside the bandwidth-bound reconstruction of the other.  A call is cut into about four chunks when it is large
     // enough for each to still fill the device's lanes (16 GB of coefficients = 20 000 images of 512x512); a smaller call is one chunk.
-    size_t min_chunk = (size_t)16 << 30, parts = 4;
+    // The walk of a chunk takes as long as its longest file (~0.65 us per entropy byte: 21 ms for 29 KB files, 236 ms for 366 KB photos)
+    // however few files it has, and walks of different chunks only overlap pairwise (two lanes): small files are cut into four chunks
+    // for the pipelining, photo-sized files into two so that the walks are not paid four times.
+    size_t max_len = 0;
+    for (uint32_t g : idx) max_len = std::max(max_len, jobs[g].len);
+    size_t min_chunk = (size_t)16 << 30, parts = 0.65e-6 * (double)max_len > 0.08 ? 2 : 4;
     if (const char *e = getenv("RPH_JPEG_CHUNK_GB")) min_chunk = (size_t)atoi(e) << 30;  // experiments
     if (const char *e = getenv("RPH_JPEG_PARTS")) parts = (size_t)atoi(e);
     const size_t chunk_target = std::min(need, std::max(need / parts + 128, min_chunk));
@@ -1174,7 +1194,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         RPH_TRY(S.meta.reserve(meta_bytes));
         ChunkDesc D;
         std::vector<size_t> subs;
-        RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, P.recon_coef_bytes[b], S.meta.h, 0, D, subs));
+        RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, false, P.recon_coef_bytes[b], S.meta.h, 0, D, subs));
         memcpy(S.meta.h + off_himg, himgs.data(), m * sizeof(HImage));
         memcpy(S.meta.h + off_order, order.data(), order.size() * 4);
         if (!luts.empty()) memcpy(S.meta.h + off_luts, luts.data(), luts.size() * sizeof(rphj::DeviceLut));
