@@ -433,13 +433,12 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
         const uint32_t lead = (uint32_t)((uintptr_t)sp & 3);
         const uint8_t *sbase = sp - lead;
         const uint32_t limit = ((slen + lead + 3) & ~3u) + 8;  // 32 zero bytes lie behind the scan: reading on is safe, and a corrupt stream reads zeros there for ever
-        auto load8 = [&](uint32_t at) -> uint64_t {
-            const W2 v = *reinterpret_cast<const W2 *>(sbase + (at < limit ? at : limit));
-            return ((uint64_t)__builtin_bswap32(v.x) << 32) | __builtin_bswap32(v.y);
-        };
+        auto load8 = [&](uint32_t at) -> W2 { return *reinterpret_cast<const W2 *>(sbase + (at < limit ? at : limit)); };
+        auto be64 = [](W2 v) -> uint64_t { return ((uint64_t)__builtin_bswap32(v.x) << 32) | __builtin_bswap32(v.y); };
         uint64_t acc = (uint64_t)(__builtin_bswap32(*reinterpret_cast<const uint32_t *>(sbase)) << (8 * lead)) << 32;
         int nb = 32 - 8 * (int)lead;
-        uint64_t q0 = load8(4), q1 = load8(12);
+        uint64_t q0 = be64(load8(4));
+        W2 q1 = load8(12);  // kept as loaded: its bytes are swapped when it becomes q0, a word later, so nothing waits on the load now
         uint32_t q0n = 64, woff = 20;
         // position: component i of the MCU, block (h, v) of the component, MCU (mx, my); k = next coefficient index (zigzag order)
         uint32_t i = 0, h = 0, v = 0, mx = 0, my = 0, k = 0, until = ri;
@@ -455,7 +454,7 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
                 q0 <<= 32;
                 q0n -= 32;
                 if (q0n == 0) {
-                    q0 = q1;
+                    q0 = be64(q1);
                     q0n = 64;
                     q1 = load8(woff);
                     woff += 8;
