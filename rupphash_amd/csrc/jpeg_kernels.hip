@@ -673,6 +673,7 @@ constexpr size_t CHUNK_COEF_BYTES = (size_t)192 << 20;   // host entropy, per sl
 constexpr size_t SUB_COEF_BYTES = (size_t)4 << 30;        // device entropy: reconstruction sub-batch (~5400 such images)
 constexpr size_t MAX_IMAGE_COEF_BYTES = (size_t)3 << 30;  // one image beyond this is refused (RPH_ERR_UNSUPPORTED)
 constexpr uint32_t CHUNK_MAX_IMAGES = 4096;               // host entropy
+constexpr size_t SUB_MAX_IMAGES = 16384;                  // images per reconstruction sub-batch (grid.y of the kernels: 3 planes each)
 constexpr uint32_t DEVICE_ENTROPY_MIN_FILES = 2048;       // automatic mode: below this the host decodes (latency)
 
 // Huffman tables of a chunk, one per distinct content (most files of a collection share the four Annex K tables)
@@ -827,16 +828,20 @@ int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first
     D.n_planes = D.n_images = 0;
     sub_starts.clear();
     sub_starts.push_back(0);
-    size_t plane_bytes = 0, out_bytes = 0, sub_blocks = 0;
+    size_t plane_bytes = 0, out_bytes = 0, sub_blocks = 0, sub_images = 0;
     for (size_t r = 0; r < m; r++) {
         Job &j = jobs[idx[first + r]];
         if (j.status != RPH_OK) continue;
         const rphj::Frame &f = j.frame;
-        if (sub_blocks && (sub_blocks + f.total_blocks) * 128 > sub_coef_bytes) {  // the sub-batch is full: offsets restart
+        // a sub-batch is full when its coefficients would not fit the reconstruction buffers, or at 16 384 images (the kernels take
+        // the plane / image index from blockIdx.y, which ends at 65 535): offsets restart
+        if (sub_blocks && ((sub_blocks + f.total_blocks) * 128 > sub_coef_bytes || sub_images == SUB_MAX_IMAGES)) {
             sub_starts.push_back(r);
             plane_bytes = out_bytes = sub_blocks = 0;
+            sub_images = 0;
         }
         sub_blocks += f.total_blocks;
+        sub_images++;
         D.n_blocks[r] = (uint32_t)f.total_blocks;
         JImage im;
         memset(&im, 0, sizeof im);

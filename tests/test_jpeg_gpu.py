@@ -162,6 +162,20 @@ def test_hash_batch_larger_than_one_chunk_and_thread_counts_agree(eng, oracle):
         assert np.array_equal(again["hash"], ref["hash"][:100])
 
 
+def test_forty_thousand_tiny_files_on_the_device_walk(eng, oracle):
+    """more images than one reconstruction sub-batch may hold (the kernels index planes / images with blockIdx.y)"""
+    base = [ju.pillow_jpeg(ju.make_image(24 + (k % 5) * 8, 16 + (k % 3) * 8, seed=k), quality=70 + k % 20, subsampling=k % 3) for k in range(30)]
+    files = [base[(k * 11) % 30] for k in range(40000)]
+    eng.jpeg_set_entropy(1)
+    out = eng.jpeg_pdq_hash_batch(files, threads=16)
+    eng.jpeg_set_entropy(2)
+    assert out["valid"].all() and not out["status"].any()
+    for k in range(30):
+        ok, h, q, _ = _oracle_hash(oracle, oracle.jpeg_decode(base[(k * 11) % 30], 0))
+        assert ok and np.array_equal(out["hash"][k], h)
+    assert np.array_equal(out["hash"][:30 * 1000].reshape(1000, 30, 32), np.broadcast_to(out["hash"][:30], (1000, 30, 32)))
+
+
 def test_default_threads_and_release(eng, oracle):
     """n_threads = 0 (affinity mask / cgroup quota decide), and the cached buffers can be returned and come back on the next call"""
     files = [ju.pillow_jpeg(ju.make_image(96 + k, 64, seed=k), quality=80) for k in range(40)]
