@@ -255,6 +255,50 @@ inline std::vector<uint64_t> generate_dihedral_hashes(uint64_t h)
 
 namespace scanner {
 constexpr int PDQ_MIN_QUALITY = RPH_PDQ_MIN_QUALITY;                                               // scanner.rs:1588
+
+// The "jpg" | "jpeg" arm of load_image_fast (scanner.rs:461-508): the decoded image (Luma8 or Rgb8, what the reference wraps into a
+// DynamicImage), or nullopt for anything the library does not take -- the caller goes on to its next decoder (scanner.rs:510-551).
+struct DecodedImage {
+    std::vector<uint8_t> pixels;
+    uint32_t width = 0, height = 0, channels = 0;
+    ImageView view() const { return ImageView{pixels.data(), width, height, channels}; }
+};
+inline std::optional<DecodedImage> load_image_fast(const uint8_t *bytes, size_t len, int flavour = RPH_JPEG_ZUNE)
+{
+    DecodedImage img;
+    if (rph_jpeg_info(bytes, len, &img.width, &img.height, &img.channels) != RPH_OK) return std::nullopt;
+    img.pixels.resize((size_t)img.width * img.height * img.channels);
+    if (rph_jpeg_decode(Context::get(), bytes, len, flavour, img.pixels.data()) != RPH_OK) return std::nullopt;
+    return img;
+}
+// A batch of files -> hashes (scan loop of scanner.rs:1202-1418 for JPEG files): hash, quality and validity per file; a file that
+// cannot be decoded here comes back with valid = false and keeps the caller's own path.
+struct FileHash {
+    pdqhash::Hash hash{};
+    float quality = 0.f;
+    bool valid = false;
+    int status = 0;
+};
+inline std::vector<FileHash> hash_jpeg_files(const std::vector<std::pair<const uint8_t *, size_t>> &files, int flavour = RPH_JPEG_ZUNE, uint32_t threads = 0)
+{
+    const uint32_t n = (uint32_t)files.size();
+    std::vector<const uint8_t *> ptr(n);
+    std::vector<size_t> len(n);
+    for (uint32_t i = 0; i < n; i++) ptr[i] = files[i].first, len[i] = files[i].second;
+    std::vector<uint8_t> hashes((size_t)n * 32), valid(n);
+    std::vector<float> quality(n);
+    std::vector<int32_t> status(n);
+    check(rph_jpeg_pdq_hash_batch(Context::get(), ptr.data(), len.data(), n, flavour, threads, hashes.data(), quality.data(), nullptr, nullptr, valid.data(), status.data()),
+          "hash_jpeg_files");
+    std::vector<FileHash> out(n);
+    for (uint32_t i = 0; i < n; i++) {
+        std::memcpy(out[i].hash.data(), &hashes[(size_t)i * 32], 32);
+        out[i].quality = quality[i];
+        out[i].valid = valid[i] != 0;
+        out[i].status = status[i];
+    }
+    return out;
+}
 inline bool is_low_pdq_quality(std::optional<uint16_t> q) { return rph_is_low_pdq_quality(q ? (int32_t)*q : -1) != 0; }  // :1592
 
 struct ScannedFile {  // the fields group_files_generic reads (scanner.rs:1610-1636)

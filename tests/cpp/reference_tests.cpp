@@ -251,6 +251,38 @@ static void grouping_rules()  // scanner.rs:1588-1594, 1640-1823
     EXPECT(threw, "similarity 64 must be rejected (scanner.rs:1650-1655)");
 }
 
+// Row N3: load_image_fast + generate_pdq_features on the reference's own bench image (tests/bench.jpg, hamminghash.rs:422), file by file
+// and as a batch of files: the same hash either way, and the decode of a one-component re-encode is Luma8
+static void jpeg_files_through_the_mirror()
+{
+    const char *root = std::getenv("RPH_TEST_GOLDEN");
+    if (!root) {
+        std::printf("jpeg_files_through_the_mirror: RPH_TEST_GOLDEN not set, skipped\n");
+        return;
+    }
+    std::vector<uint8_t> bytes;
+    {
+        const std::string path = std::string(root) + "/bench.jpg";
+        FILE *f = std::fopen(path.c_str(), "rb");
+        EXPECT(f != nullptr, "f != nullptr");
+        if (!f) return;
+        uint8_t buf[65536];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) bytes.insert(bytes.end(), buf, buf + got);
+        std::fclose(f);
+    }
+    const auto img = rupphash::scanner::load_image_fast(bytes.data(), bytes.size());
+    EXPECT(img.has_value(), "img.has_value()");
+    if (!img) return;
+    EXPECT(img->width == 1280 && img->height == 854 && img->channels == 3, "img->width == 1280 && img->height == 854 && img->channels == 3");
+    const auto one = rupphash::pdqhash::generate_pdq(img->view());
+    EXPECT(one.has_value(), "one.has_value()");
+    const auto batch = rupphash::scanner::hash_jpeg_files({{bytes.data(), bytes.size()}, {bytes.data(), 100}, {bytes.data(), bytes.size()}});
+    EXPECT(batch.size() == 3 && batch[0].valid && !batch[1].valid && batch[1].status != 0 && batch[2].valid, "batch.size() == 3 && batch[0].valid && !batch[1].valid && batch[1].status != 0 && batch[2].valid");
+    if (one) EXPECT(batch[0].hash == one->first && batch[2].hash == one->first && batch[0].quality == one->second, "batch[0].hash == one->first && batch[2].hash == one->first && batch[0].quality == one->second");
+    EXPECT(!rupphash::scanner::load_image_fast(bytes.data(), 100).has_value(), "!rupphash::scanner::load_image_fast(bytes.data(), 100).has_value()");  // truncated header: the caller's next decoder takes it
+}
+
 int main()
 {
     fast_dihedral_matches_naive();
@@ -262,6 +294,7 @@ int main()
     test_injected_cluster();
     phash_known_answer();
     grouping_rules();
+    jpeg_files_through_the_mirror();
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
     return failures;
 }

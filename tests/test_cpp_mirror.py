@@ -24,6 +24,7 @@ def test_cpp_mirror_compiles():
 def test_reference_unit_tests_through_cpp_mirror():
     if not os.path.exists(BIN):
         build_cpp_tests()
-    r = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, RPH_TEST_GOLDEN=os.path.join(ROOT, "tests", "golden"))
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=600, env=env)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
