@@ -47,3 +47,26 @@ def test_prophecy_pair_gpu_equals_oracle(oracle):
     groups, _ = eng.group_files_pdq(np.stack([got[0][0], got[1][0]]), 40)
     assert (groups == [[0, 1]]) == (d <= 40)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_prophecy_pair_from_the_file_bytes(oracle, flavour):
+    """config 1 without a host decoder in the loop: the JPEG bytes go to rph_jpeg_pdq_hash_batch (row N3); decode arithmetic of
+    zune-jpeg as recalled (0, parity unpinned) or of libjpeg-turbo (1, == the Pillow decode the tests above use)"""
+    from rupphash_amd import Engine, hamminghash
+
+    eng = Engine(0)
+    files = [open(os.path.join(GOLDEN, f"Prophecy_Has_Been_Fulfilled_{k}.jpg"), "rb").read() for k in (1, 2)]
+    out = eng.jpeg_pdq_hash_batch(files, flavour=flavour, threads=2)
+    assert out["valid"].all()
+    for k in range(2):
+        rc, coeffs, q = oracle.pdq_features(oracle.jpeg_decode(files[k], flavour))
+        assert rc == 0 and np.array_equal(out["hash"][k], oracle.to_hash(coeffs)) and out["quality"][k] == np.float32(q)
+    d = hamminghash.hamming_distance(out["hash"][0], out["hash"][1])
+    print(f"config 1 (GPU, from the file bytes, flavour {flavour}): Hamming distance {d}")
+    if flavour == 1:
+        pil = [oracle.to_hash(oracle.pdq_features(im)[1]) for im in load()]
+        assert np.array_equal(out["hash"][0], pil[0]) and np.array_equal(out["hash"][1], pil[1])  # same pixels as Pillow, hence the same hashes
+    assert d <= 63
+    eng.close()
