@@ -584,7 +584,6 @@ int walk(const uint8_t *data, size_t len, Frame &f, Decoder *dec)
 int parse_frame(const uint8_t *data, size_t len, Frame &f)
 {
     f = Frame();
-    memset(f.qt, 0, sizeof f.qt);
     return walk(data, len, f, nullptr);
 }
 

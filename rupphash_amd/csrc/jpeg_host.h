@@ -17,6 +17,7 @@ struct Comp {
 };
 
 struct Frame {
+    Frame() {}  // user-provided: the quantisation tables (512 bytes) are not cleared per file; qt_present says which ones are there
     uint32_t w = 0, h = 0;
     int ncomp = 0;
     bool progressive = false, have_sof = false;

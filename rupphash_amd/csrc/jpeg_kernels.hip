@@ -704,6 +704,7 @@ struct TableStore {
 };
 
 struct Job {
+    Job() {}  // user-provided on purpose: std::vector<Job>(n) then runs the member initialisers only instead of zeroing ~1 KB per job first
     const uint8_t *data = nullptr;
     size_t len = 0;
     rphj::Frame frame;
@@ -1377,7 +1378,12 @@ int rph_jpeg_coefficients(const uint8_t *data, size_t len, uint32_t *geometry, u
             uint32_t *g = geometry + 8 * c;
             g[0] = k.blocks_w, g[1] = k.blocks_h, g[2] = k.H, g[3] = k.V, g[4] = k.tq, g[5] = k.samp_w, g[6] = k.samp_h, g[7] = (uint32_t)k.first_block;
         }
-        memcpy(qt, f.qt, sizeof f.qt);
+        for (int t = 0; t < 4; t++) {
+            if (f.qt_present[t])
+                memcpy(qt + 64 * t, f.qt[t], 128);
+            else
+                memset(qt + 64 * t, 0, 128);
+        }
         return RPH_OK;
     });
 }
