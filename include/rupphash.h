@@ -350,6 +350,14 @@ int rph_jpeg_pdq_hash_batch(rph_ctx *ctx, const uint8_t *const *data, const size
                             uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *dihedral_out, uint8_t *valid_out,
                             int32_t *status_out);
 
+/* The same for ONE file per call, from any number of threads at once (the reference's scan loop as it stands: load_image_fast +
+ * generate_pdq_features on every rayon worker, scanner.rs:1202, :1410): blocking.  The calling thread undoes the entropy coding of
+ * its file itself (into a pinned buffer it keeps for its lifetime); callers that arrive while a batch is on the device leave
+ * together as the next batch.  Returns the file's status (RPH_OK with *valid_out = 0: below 5 px); quality_out, coeffs_out
+ * (256 floats) and valid_out may be NULL. */
+int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int flavour, uint8_t *hash32_out, float *quality_out, float *coeffs_out,
+                          uint8_t *valid_out);
+
 /* Where rph_jpeg_pdq_hash_batch decodes the Huffman streams of sequential (baseline) files:
  *   RPH_JPEG_ENTROPY_HOST (0)    n_threads host threads, one file each; the coefficients cross PCIe (0.8 MB per 512x512 file);
  *   RPH_JPEG_ENTROPY_DEVICE (1)  on the device, one file per lane: the host only copies the entropy bytes (stuffing undone) and the

@@ -711,6 +711,7 @@ struct Job {
     int status = RPH_OK;
     uint64_t first_block = 0;  // within the chunk's coefficient buffer
     rphj::StreamPlan plan;     // device entropy
+    const int16_t *pre = nullptr;  // coefficients already decoded by the caller into pinned memory (rph_jpeg_pdq_hash_one)
     size_t stream_off = 0, stream_used = 0;
 };
 
@@ -1019,17 +1020,28 @@ int run_host_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, const std::vector<ui
             }
         }
         int16_t *h_coef = reinterpret_cast<int16_t *>(S.coef.h);
-        parallel_for(first, last, threads, [&](size_t i) {
-            Job &j = jobs[idx[i]];
-            if (j.status == RPH_OK) j.status = rphj::decode_coefficients(j.data, j.len, j.frame, h_coef + j.first_block * 64);
-        });
+        bool predecoded = false;
+        for (size_t i = first; i < last; i++) predecoded |= jobs[idx[i]].pre != nullptr;
+        if (!predecoded)
+            parallel_for(first, last, threads, [&](size_t i) {
+                Job &j = jobs[idx[i]];
+                if (j.status == RPH_OK) j.status = rphj::decode_coefficients(j.data, j.len, j.frame, h_coef + j.first_block * 64);
+            });
         ChunkDesc D;
         std::vector<size_t> subs;
         RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, out.pixels != nullptr, SIZE_MAX / 256, S.meta.h, 0, D, subs));
         hipStream_t s = S.stream;
         RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
         if (D.n_images) {
-            RPH_HIP_CHECK(hipMemcpyAsync(S.coef.d, S.coef.h, blocks * 128, hipMemcpyHostToDevice, s));
+            if (predecoded) {  // every caller decoded into its own pinned buffer: the copy engine takes the coefficients from there
+                for (size_t i = first; i < last; i++) {
+                    const Job &j = jobs[idx[i]];
+                    if (j.status == RPH_OK)
+                        RPH_HIP_CHECK(hipMemcpyAsync(S.coef.d + j.first_block * 128, j.pre, (size_t)j.frame.total_blocks * 128, hipMemcpyHostToDevice, s));
+                }
+            } else {
+                RPH_HIP_CHECK(hipMemcpyAsync(S.coef.d, S.coef.h, blocks * 128, hipMemcpyHostToDevice, s));
+            }
             RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, D.off_end, hipMemcpyHostToDevice, s));
             RPH_TRY(reconstruct_and_hash(ctx, P, b, S, jobs, idx, first, D, 0, m, reinterpret_cast<const int16_t *>(S.coef.d), flavour, out, s));
         }
@@ -1259,7 +1271,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     return RPH_OK;
 }
 
-int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint32_t n, int flavour, uint32_t n_threads, Outputs out)
+int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint32_t n, int flavour, uint32_t n_threads, Outputs out, Jobs *prepared = nullptr)
 {
     if (flavour != RPH_JPEG_ZUNE && flavour != RPH_JPEG_LIBJPEG) {
         rph_set_error("rph_jpeg: unknown flavour %d", flavour);
@@ -1274,20 +1286,22 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
 
     g_trace_t0 = now_ms();
     RPH_JPEG_STAMP("call: %u files", n);
-    Jobs jobs(n);  // (first-touching the storage from the parsing threads instead is 5x slower: page faults under contention)
-    parallel_for(0, n, n >= 1024 ? threads : 1, [&](size_t i) {
-        Job &j = jobs[i];
-        j.data = data[i];
-        j.len = len[i];
-        j.status = (j.data && j.len) ? rphj::parse_frame(j.data, j.len, j.frame) : RPH_ERR_INVALID_ARG;
-        if (j.status == RPH_OK && j.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) j.status = RPH_ERR_UNSUPPORTED;
-    });
+    Jobs local(prepared ? 0 : n);  // (first-touching the storage from the parsing threads instead is 5x slower: page faults under contention)
+    Jobs &jobs = prepared ? *prepared : local;
+    if (!prepared)
+        parallel_for(0, n, n >= 1024 ? threads : 1, [&](size_t i) {
+            Job &j = jobs[i];
+            j.data = data[i];
+            j.len = len[i];
+            j.status = (j.data && j.len) ? rphj::parse_frame(j.data, j.len, j.frame) : RPH_ERR_INVALID_ARG;
+            if (j.status == RPH_OK && j.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) j.status = RPH_ERR_UNSUPPORTED;
+        });
     RPH_JPEG_STAMP("frames parsed");
     // which files walk their Huffman streams on the device: sequential ones, when the batch is large enough to fill lanes
     std::vector<uint32_t> host_idx, dev_idx;
     for (uint32_t i = 0; i < n; i++) {
         const Job &j = jobs[i];
-        if (j.status == RPH_OK && !j.frame.progressive && ctx->jpeg_entropy != 0 && out.want_hash)
+        if (j.status == RPH_OK && !j.frame.progressive && ctx->jpeg_entropy != 0 && out.want_hash && !prepared)
             dev_idx.push_back(i);
         else
             host_idx.push_back(i);
@@ -1422,6 +1436,128 @@ int rph_jpeg_decode(rph_ctx *ctx, const uint8_t *data, size_t len, int flavour, 
         o.pixels = pixels_out;
         o.want_hash = false;
         return run_batch(ctx, &data, &len, 1, flavour, 1, o);
+    });
+}
+
+// One file per call from many threads (the reference's scan loop: load_image_fast + generate_pdq_features on every rayon worker,
+// scanner.rs:1202, :1410).  Callers that arrive while a batch is on its way wait and leave together as the next batch, which one of
+// them (the leader) runs through the reconstruction + hashing stages of rph_jpeg_pdq_hash_batch.  Every caller undoes the entropy
+// coding of its own file first, on its own core, into a pinned buffer of its own that the copy engine reads directly.
+namespace {
+struct OneRequest {
+    const uint8_t *data;
+    size_t len;
+    int flavour;
+    rphj::Frame frame;
+    const int16_t *coef;  // the caller's pinned buffer, decoded by the caller
+    uint8_t hash[32];
+    float quality, coeffs[256];
+    uint8_t valid;
+    int32_t status;
+    bool want_coeffs, done;
+};
+// One pinned coefficient buffer per calling thread, kept for the thread's life (a scan worker decodes thousands of files into it)
+struct ThreadPinned {
+    int16_t *p = nullptr;
+    size_t cap = 0;
+    ~ThreadPinned()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+};
+thread_local ThreadPinned tls_coef;
+}  // namespace
+
+int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int flavour, uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *valid_out)
+{
+    return rph_guarded("rph_jpeg_pdq_hash_one", [&]() -> int {
+        if (!ctx || !data || !hash32_out || (flavour != RPH_JPEG_ZUNE && flavour != RPH_JPEG_LIBJPEG)) {
+            rph_set_error("rph_jpeg_pdq_hash_one: invalid argument");
+            return RPH_ERR_INVALID_ARG;
+        }
+        // ---- this thread: frame header and entropy decoding into its own pinned buffer (all callers do this side by side)
+        OneRequest me;
+        me.data = data, me.len = len, me.flavour = flavour, me.want_coeffs = coeffs_out != nullptr, me.done = false, me.valid = 0, me.quality = 0.f, me.coef = nullptr;
+        me.status = rphj::parse_frame(data, len, me.frame);
+        if (me.status == RPH_OK && me.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) me.status = RPH_ERR_UNSUPPORTED;
+        if (me.status == RPH_OK) {
+            const size_t need = (size_t)me.frame.total_blocks * 128;
+            if (tls_coef.cap < need) {
+                RPH_HIP_CHECK(hipSetDevice(ctx->device));
+                if (tls_coef.p) (void)hipHostFree(tls_coef.p);
+                tls_coef.p = nullptr, tls_coef.cap = 0;
+                const size_t cap = align_up(need + need / 2, 1 << 20);
+                RPH_HIP_CHECK(hipHostMalloc((void **)&tls_coef.p, cap));
+                tls_coef.cap = cap;
+            }
+            me.status = rphj::decode_coefficients(data, len, me.frame, tls_coef.p);
+            me.coef = tls_coef.p;
+        }
+        if (me.status != RPH_OK) {
+            memset(hash32_out, 0, 32);
+            if (quality_out) *quality_out = 0.f;
+            if (coeffs_out) memset(coeffs_out, 0, 1024);
+            if (valid_out) *valid_out = 0;
+            rph_set_error("rph_jpeg_pdq_hash_one: not decodable here (status %d)", me.status);
+            return me.status;
+        }
+        // ---- the device part: with everyone else who is waiting, as one batch, run by one of them
+        std::unique_lock<std::mutex> lk(ctx->jpeg_qmu);
+        ctx->jpeg_waiting.push_back(&me);
+        while (!me.done) {
+            if (ctx->jpeg_leader) {
+                ctx->jpeg_qcv.wait(lk);
+                continue;
+            }
+            ctx->jpeg_leader = true;
+            std::vector<void *> batch;
+            batch.swap(ctx->jpeg_waiting);
+            lk.unlock();
+            for (int fl = 0; fl < 2; fl++) {  // (callers may ask for different arithmetic flavours: one pass each)
+                std::vector<OneRequest *> reqs;
+                for (void *p : batch)
+                    if (static_cast<OneRequest *>(p)->flavour == fl) reqs.push_back(static_cast<OneRequest *>(p));
+                if (reqs.empty()) continue;
+                const uint32_t n = (uint32_t)reqs.size();
+                int rc = RPH_OK;
+                std::vector<uint8_t> hashes((size_t)n * 32), valid(n);
+                std::vector<float> quality(n), coeffs;
+                std::vector<int32_t> status(n);
+                try {
+                    bool any_coeffs = false;
+                    Jobs jobs(n);
+                    for (uint32_t i = 0; i < n; i++) {
+                        jobs[i].data = reqs[i]->data, jobs[i].len = reqs[i]->len, jobs[i].frame = reqs[i]->frame, jobs[i].pre = reqs[i]->coef;
+                        any_coeffs |= reqs[i]->want_coeffs;
+                    }
+                    coeffs.resize(any_coeffs ? (size_t)n * 256 : 0);
+                    Outputs o;
+                    o.hash = hashes.data(), o.quality = quality.data(), o.coeffs = any_coeffs ? coeffs.data() : nullptr, o.valid = valid.data(), o.status = status.data();
+                    rc = run_batch(ctx, nullptr, nullptr, n, fl, 1, o, &jobs);
+                } catch (...) {
+                    rc = RPH_ERR_OOM;
+                }
+                for (uint32_t i = 0; i < n; i++) {
+                    OneRequest &r = *reqs[i];
+                    r.status = (rc != RPH_OK && status[i] == RPH_OK) ? rc : status[i];  // a failure of the call itself fails all of its files
+                    memcpy(r.hash, &hashes[(size_t)i * 32], 32);
+                    r.quality = quality[i];
+                    r.valid = r.status == RPH_OK ? valid[i] : 0;
+                    if (r.want_coeffs && !coeffs.empty()) memcpy(r.coeffs, &coeffs[(size_t)i * 256], 1024);
+                }
+            }
+            lk.lock();
+            for (void *p : batch) static_cast<OneRequest *>(p)->done = true;
+            ctx->jpeg_leader = false;
+            ctx->jpeg_qcv.notify_all();
+        }
+        lk.unlock();
+        memcpy(hash32_out, me.hash, 32);
+        if (quality_out) *quality_out = me.quality;
+        if (coeffs_out) memcpy(coeffs_out, me.coeffs, 1024);
+        if (valid_out) *valid_out = me.valid;
+        if (me.status != RPH_OK) rph_set_error("rph_jpeg_pdq_hash_one: failed (status %d)", me.status);
+        return me.status;
     });
 }
 

@@ -2,10 +2,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <condition_variable>
 #include <exception>
 #include <map>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "../../include/rupphash.h"
 
@@ -57,6 +59,11 @@ struct rph_ctx {
     // where the Huffman streams of sequential files are decoded: 0 = host threads, 1 = device (one image per lane), 2 = automatic
     // (device from 2048 sequential files per call: the walk of one image is serial, so it needs tens of thousands of images in flight)
     int jpeg_entropy = 2;
+    // rph_jpeg_pdq_hash_one: callers that arrive while a batch is on its way wait here and leave together as the next batch
+    std::mutex jpeg_qmu;
+    std::condition_variable jpeg_qcv;
+    std::vector<void *> jpeg_waiting;
+    bool jpeg_leader = false;
 };
 
 void rph_set_error(const char *fmt, ...);

@@ -123,6 +123,17 @@ class Engine:
         """0 = Huffman streams decoded by host threads, 1 = on the device (one file per lane), 2 = automatic (default)"""
         check(self.L.rph_jpeg_set_entropy(self.ctx, int(where)), "rph_jpeg_set_entropy")
 
+    def jpeg_pdq_hash_one(self, data, flavour=0, want_coeffs=True):
+        """One JPEG file per call, thread-safe (concurrent callers share a batch): (hash, quality, coeffs or None), None when the image is
+        below 5 px; raises RphError for a file the library does not decode."""
+        hash32 = np.zeros(32, np.uint8)
+        q = C.c_float()
+        coeffs = np.zeros(256, np.float32) if want_coeffs else None
+        valid = C.c_uint8()
+        check(self.L.rph_jpeg_pdq_hash_one(self.ctx, data, len(data), int(flavour), _ptr(hash32), C.cast(C.byref(q), C.c_void_p), _ptr(coeffs),
+                                           C.cast(C.byref(valid), C.c_void_p)), "rph_jpeg_pdq_hash_one")
+        return (hash32, q.value, coeffs) if valid.value else None
+
     def jpeg_release(self):
         """give the JPEG path's cached staging / device buffers back"""
         check(self.L.rph_jpeg_release(self.ctx), "rph_jpeg_release")

@@ -176,6 +176,49 @@ def test_forty_thousand_tiny_files_on_the_device_walk(eng, oracle):
     assert np.array_equal(out["hash"][:30 * 1000].reshape(1000, 30, 32), np.broadcast_to(out["hash"][:30], (1000, 30, 32)))
 
 
+def test_one_file_per_call_from_many_threads(eng, oracle):
+    """rph_jpeg_pdq_hash_one from 12 threads at once (the scan loop's pattern): same hashes, qualities and coefficients as the batch call;
+    a too-small image gives None, an undecodable file raises"""
+    import threading
+
+    from rupphash_amd import RphError
+
+    files = [ju.pillow_jpeg(ju.make_image(64 + 8 * (k % 9), 48 + 8 * (k % 5), "L" if k % 7 == 0 else "RGB", seed=k), quality=60 + k % 35,
+                            progressive=bool(k % 4 == 1)) for k in range(96)]
+    files[10] = ju.pillow_jpeg(ju.make_image(4, 30))          # below 5 px
+    files[20] = b"\xff\xd8 nothing of a JPEG follows"          # not decodable
+    ref = eng.jpeg_pdq_hash_batch(files, threads=4, want_coeffs=True)
+    got, errors = [None] * len(files), []
+
+    def worker(t):
+        for i in range(t, len(files), 12):
+            try:
+                got[i] = eng.jpeg_pdq_hash_one(files[i], flavour=1 if i == 4 else 0)
+            except RphError as e:
+                got[i] = e
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors
+    for i in range(len(files)):
+        if i == 10:
+            assert got[i] is None and ref["valid"][i] == 0 and ref["status"][i] == 0
+        elif i == 20:
+            assert isinstance(got[i], RphError) and ref["status"][i] != 0
+        elif i == 4:  # asked for the other flavour
+            ok, h, _, _ = _oracle_hash(oracle, oracle.jpeg_decode(files[i], 1))
+            assert ok and np.array_equal(got[i][0], h)
+        else:
+            h, q, c = got[i]
+            assert np.array_equal(h, ref["hash"][i]) and np.float32(q).view(np.uint32) == ref["quality"][i].view(np.uint32), i
+            assert np.array_equal(c.view(np.uint32), ref["coeffs"][i].view(np.uint32)), i
+
+
 def test_default_threads_and_release(eng, oracle):
     """n_threads = 0 (affinity mask / cgroup quota decide), and the cached buffers can be returned and come back on the next call"""
     files = [ju.pillow_jpeg(ju.make_image(96 + k, 64, seed=k), quality=80) for k in range(40)]
