@@ -287,6 +287,14 @@ int rph_multi_hash_and_group(rph_multi *multi, const uint8_t *px, uint32_t n, ui
                              size_t row_stride, size_t image_stride, uint32_t similarity, uint8_t *hash32_out, float *quality_out,
                              float *coeffs_out, uint8_t *valid_out, uint32_t *members, uint32_t *offsets, uint32_t *n_groups_out,
                              uint64_t *comparison_count_out);
+/* The same from JPEG FILES in host memory (rows N3 + B6 in one call): device i decodes and hashes files [lo_i, hi_i) as
+ * rph_jpeg_pdq_hash_batch does (n_threads host threads in all, 0 = what the process may use per device), then the files that
+ * produced a hash are grouped as above; members are indices into the caller's file list.  quality_out / coeffs_out / valid_out /
+ * status_out are nullable. */
+int rph_multi_jpeg_hash_and_group(rph_multi *multi, const uint8_t *const *data, const size_t *len, uint32_t n, int flavour, uint32_t n_threads,
+                                  uint32_t similarity, uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *valid_out,
+                                  int32_t *status_out, uint32_t *members, uint32_t *offsets, uint32_t *n_groups_out,
+                                  uint64_t *comparison_count_out);
 /* rph_group_files_pdq across the devices: hashes / coefficients / quality from the cache (same arguments and results). */
 int rph_multi_group_files_pdq(rph_multi *multi, const uint8_t *hashes32, const float *coeffs, const uint8_t *has_features,
                               const int32_t *quality, uint64_t n, uint32_t similarity, uint32_t *members, uint32_t *offsets,

@@ -94,6 +94,8 @@ SIGNATURES = {
     "rph_multi_hamming_all_pairs": (C.c_int, [_vp, _u8p, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rph_multi_hash_and_group": (C.c_int, [_vp, _u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _sz, _sz, C.c_uint32, _u8p, _f32p, _f32p, _u8p,
                                            _u32p, _u32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "rph_multi_jpeg_hash_and_group": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, _u8p, _f32p, _f32p, _u8p,
+                                              _i32p, _u32p, _u32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "rph_multi_group_files_pdq": (C.c_int, [_vp, _u8p, _f32p, _u8p, _i32p, C.c_uint64, C.c_uint32, _u32p, _u32p, C.POINTER(C.c_uint32),
                                             C.POINTER(C.c_uint64)]),
     "rph_hash_record_encode": (None, [_u8p, _u8p]),

@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -373,6 +374,82 @@ int rph_multi_hash_and_group(rph_multi *m, const uint8_t *px, uint32_t n, uint32
         RPH_TRY(sweep_all(m, rows, 8, hashes, low, none, n, similarity, edges));
         if (comparison_count_out) *comparison_count_out = edges.size();
         return rph_host_union_find(edges.data(), edges.size(), n, members, offsets, n_groups_out);
+    });
+}
+
+// The scan-then-group call from the FILES: every device decodes and hashes a contiguous range of the JPEG files (rph_jpeg_pdq_hash_batch:
+// no communication), then the grouping of rph_multi_group_files_pdq over the files that produced a hash (the reference groups
+// `valid_entries`, scanner.rs:1658-1662), whose one exchange is the all-gather of the dihedral blocks.
+int rph_multi_jpeg_hash_and_group(rph_multi *m, const uint8_t *const *data, const size_t *len, uint32_t n, int flavour, uint32_t n_threads, uint32_t similarity,
+                                  uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *valid_out, int32_t *status_out, uint32_t *members,
+                                  uint32_t *offsets, uint32_t *n_groups_out, uint64_t *comparison_count_out)
+{
+    return rph_guarded("rph_multi_jpeg_hash_and_group", [&]() -> int {
+        if (!m || (n && (!data || !len)) || !hash32_out || !members || !offsets || !n_groups_out) {
+            rph_set_error("rph_multi_jpeg_hash_and_group: null argument");
+            return RPH_ERR_INVALID_ARG;
+        }
+        if (similarity > RPH_MAX_SIMILARITY_256) {
+            rph_set_error("Similarity distances above %u require R=4 bit-flip checks, which are not implemented.", RPH_MAX_SIMILARITY_256);
+            return RPH_ERR_INVALID_ARG;
+        }
+        *n_groups_out = 0;
+        offsets[0] = 0;
+        if (comparison_count_out) *comparison_count_out = 0;
+        if (n == 0) return RPH_OK;
+        std::vector<float> q_tmp, c_tmp;
+        std::vector<uint8_t> v_tmp;
+        float *quality = quality_out, *coeffs = coeffs_out;
+        uint8_t *valid = valid_out;
+        if (!quality) q_tmp.resize(n), quality = q_tmp.data();
+        if (!coeffs) c_tmp.resize((size_t)n * 256), coeffs = c_tmp.data();
+        if (!valid) v_tmp.resize(n), valid = v_tmp.data();
+        {
+            std::lock_guard<std::mutex> lock(m->mu);
+            const int world = (int)m->ctx.size();
+            const uint32_t threads_each = n_threads ? std::max(1u, n_threads / (uint32_t)world) : 0;
+            std::vector<int> rcs(world, RPH_OK);
+            std::vector<std::string> errs(world);
+            std::vector<std::thread> th;
+            for (int i = 0; i < world; i++)
+                th.emplace_back([&, i] {
+                    uint64_t lo, hi;
+                    shard_range(n, i, world, lo, hi);
+                    if (hi == lo) return;
+                    rcs[i] = rph_jpeg_pdq_hash_batch(m->ctx[i], data + lo, len + lo, (uint32_t)(hi - lo), flavour, threads_each, hash32_out + lo * 32, quality + lo, coeffs + lo * 256,
+                                                     nullptr, valid + lo, status_out ? status_out + lo : nullptr);
+                    if (rcs[i] != RPH_OK) errs[i] = rph_last_error();
+                });
+            for (auto &t : th) t.join();
+            for (int i = 0; i < world; i++)
+                if (rcs[i] != RPH_OK) {
+                    rph_set_error("device %d: %s", m->devices[i], errs[i].c_str());
+                    return rcs[i];
+                }
+        }
+        // dense ids over the files that have a hash; stored quality = (q * 100).round().clamp(0, 100) (scanner.rs:1416-1417)
+        std::vector<uint32_t> dense_to_file;
+        for (uint32_t i = 0; i < n; i++)
+            if (valid[i]) dense_to_file.push_back(i);
+        const uint64_t nd = dense_to_file.size();
+        if (nd < 2) return RPH_OK;
+        std::vector<uint8_t> h((size_t)nd * 32);
+        std::vector<float> c((size_t)nd * 256);
+        std::vector<int32_t> q(nd);
+        for (uint64_t d = 0; d < nd; d++) {
+            const uint32_t f = dense_to_file[d];
+            memcpy(&h[d * 32], hash32_out + (size_t)f * 32, 32);
+            memcpy(&c[d * 256], coeffs + (size_t)f * 256, 1024);
+            const float s = quality[f] * 100.0f;
+            q[d] = (int32_t)std::min(100.0f, std::max(0.0f, floorf(s + 0.5f)));
+        }
+        std::vector<uint32_t> mem(nd), off(nd / 2 + 2);
+        uint32_t ng = 0;
+        RPH_TRY(rph_multi_group_files_pdq(m, h.data(), c.data(), nullptr, q.data(), nd, similarity, mem.data(), off.data(), &ng, comparison_count_out));
+        for (uint32_t g = 0; g <= ng; g++) offsets[g] = off[g];
+        for (uint32_t t = 0; t < off[ng]; t++) members[t] = dense_to_file[mem[t]];
+        *n_groups_out = ng;
+        return RPH_OK;
     });
 }
 

@@ -496,6 +496,23 @@ class MultiEngine:
         out["comparison_count"] = cmp_count.value
         return out
 
+    def jpeg_hash_and_group(self, files, similarity, flavour=0, threads=0):
+        """files: list of JPEG byte strings.  Returns dict(hash, quality, coeffs, valid, status, groups, comparison_count); groups hold
+        indices into `files` (only files that produced a hash are grouped)."""
+        arr, lens, n = files if isinstance(files, tuple) else Engine.jpeg_file_list(files)
+        out = {"hash": np.zeros((n, 32), np.uint8), "quality": np.zeros(n, np.float32), "coeffs": np.zeros((n, 256), np.float32),
+               "valid": np.zeros(n, np.uint8), "status": np.zeros(n, np.int32)}
+        members = np.zeros(max(n, 1), np.uint32)
+        offsets = np.zeros(n // 2 + 2, np.uint32)
+        ng = C.c_uint32()
+        cmp_count = C.c_uint64()
+        check(self.L.rph_multi_jpeg_hash_and_group(self.m, arr, lens, n, int(flavour), int(threads), similarity, _ptr(out["hash"]), _ptr(out["quality"]),
+                                                   _ptr(out["coeffs"]), _ptr(out["valid"]), _ptr(out["status"]), _ptr(members), _ptr(offsets), C.byref(ng),
+                                                   C.byref(cmp_count)), "rph_multi_jpeg_hash_and_group")
+        out["groups"] = Engine._groups(members, offsets, ng.value)
+        out["comparison_count"] = cmp_count.value
+        return out
+
     def group_files_pdq(self, hashes, similarity, coeffs=None, has_features=None, quality=None):
         hashes = np.ascontiguousarray(hashes, np.uint8).reshape(-1, 32)
         n = len(hashes)

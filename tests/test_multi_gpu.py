@@ -84,3 +84,43 @@ def test_multi_init_rejects_a_missing_device():
 
     with pytest.raises(RphError):
         MultiEngine(devices=[0, 99])
+
+
+def test_multi_jpeg_hash_and_group_equals_decode_then_group_on_the_cpu(multi, oracle):
+    """scan-then-group from JPEG FILES: near duplicates (the same picture at two qualities, its rotated copy), unrelated pictures, a file
+    that cannot be decoded and one below 5 px; groups are indices into the caller's file list"""
+    import jpeg_util as ju
+    from PIL import Image
+
+    pics = [ju.make_image(200 + 16 * (k % 4), 160, seed=100 + k) for k in range(12)]
+    files = []
+    for k, im in enumerate(pics):
+        files.append(ju.pillow_jpeg(im, quality=90, subsampling=2))
+        if k < 6:
+            files.append(ju.pillow_jpeg(im, quality=70, subsampling=0, progressive=bool(k % 2)))   # re-coded
+        if k < 3:
+            files.append(ju.pillow_jpeg(im.transpose(Image.ROTATE_90), quality=85))                 # rotated: found through the dihedral variants
+    files.insert(4, b"\xff\xd8 not a JPEG")
+    files.insert(9, ju.pillow_jpeg(ju.make_image(4, 40)))
+    sim = 40
+    res = multi.jpeg_hash_and_group(files, sim, threads=4)
+    dense, hashes, coeffs, stored = [], [], [], []
+    for i, f in enumerate(files):
+        try:
+            rc, c, q = oracle.pdq_features(oracle.jpeg_decode(f, 0))
+        except ValueError:
+            assert res["status"][i] != 0 and not res["valid"][i]
+            continue
+        assert bool(res["valid"][i]) == (rc == 0)
+        if rc != 0:
+            continue
+        assert np.array_equal(res["hash"][i], oracle.to_hash(c))
+        dense.append(i)
+        hashes.append(oracle.to_hash(c))
+        coeffs.append(c)
+        stored.append(int(np.clip(np.floor(np.float32(q) * np.float32(100.0) + np.float32(0.5)), 0, 100)))
+    dih = np.stack([oracle.dihedral_hashes(c) for c in coeffs])
+    edges, groups = oracle.group_pdq(np.stack(hashes), sim, variants=dih, quality=np.array(stored, np.int32))
+    want = [[dense[m] for m in g] for g in groups]
+    assert res["groups"] == want and res["comparison_count"] == len(edges)
+    assert len(want) >= 6 and any(len(g) == 3 for g in want)  # picture + re-coded + rotated copy
