@@ -1330,6 +1330,12 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
 
 }  // namespace
 
+void rph_jpeg_forget_threads(rph_ctx *ctx)  // rph_shutdown: no caller is inside the library any more
+{
+    for (void *p : ctx->jpeg_thread_buffers) (void)hipHostFree(p);
+    ctx->jpeg_thread_buffers.clear();
+}
+
 void rph_jpeg_forget(rph_ctx *ctx)
 {
     if (ctx->jpeg) {
@@ -1456,14 +1462,14 @@ struct OneRequest {
     int32_t status;
     bool want_coeffs, done;
 };
-// One pinned coefficient buffer per calling thread, kept for the thread's life (a scan worker decodes thousands of files into it)
+// One pinned coefficient buffer per calling thread (a scan worker decodes thousands of files into it).  It belongs to the context:
+// rph_shutdown frees it (a thread-local destructor would call into the HIP runtime at thread or process exit, possibly after the
+// runtime is gone); `serial` tells a later context at the same address from the one that owned the buffer.
 struct ThreadPinned {
     int16_t *p = nullptr;
     size_t cap = 0;
-    ~ThreadPinned()
-    {
-        if (p) (void)hipHostFree(p);
-    }
+    rph_ctx *owner = nullptr;
+    uint64_t serial = 0;
 };
 thread_local ThreadPinned tls_coef;
 }  // namespace
@@ -1482,13 +1488,22 @@ int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int fla
         if (me.status == RPH_OK && me.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) me.status = RPH_ERR_UNSUPPORTED;
         if (me.status == RPH_OK) {
             const size_t need = (size_t)me.frame.total_blocks * 128;
+            if (tls_coef.owner != ctx || tls_coef.serial != ctx->serial) tls_coef = ThreadPinned();  // another (or an earlier) context's buffer is not ours to use
             if (tls_coef.cap < need) {
                 RPH_HIP_CHECK(hipSetDevice(ctx->device));
-                if (tls_coef.p) (void)hipHostFree(tls_coef.p);
-                tls_coef.p = nullptr, tls_coef.cap = 0;
+                std::lock_guard<std::mutex> reg(ctx->jpeg_qmu);
+                if (tls_coef.p) {
+                    auto &v = ctx->jpeg_thread_buffers;
+                    v.erase(std::remove(v.begin(), v.end(), (void *)tls_coef.p), v.end());
+                    (void)hipHostFree(tls_coef.p);
+                }
+                tls_coef = ThreadPinned();
                 const size_t cap = align_up(need + need / 2, 1 << 20);
                 RPH_HIP_CHECK(hipHostMalloc((void **)&tls_coef.p, cap));
                 tls_coef.cap = cap;
+                tls_coef.owner = ctx;
+                tls_coef.serial = ctx->serial;
+                ctx->jpeg_thread_buffers.push_back(tls_coef.p);
             }
             me.status = rphj::decode_coefficients(data, len, me.frame, tls_coef.p);
             me.coef = tls_coef.p;

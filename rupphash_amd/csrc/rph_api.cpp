@@ -2,6 +2,7 @@
 // Host-pointer entry points stage through device memory and call the *_dev twins; there is no
 // CPU implementation of any kernel behind this API.
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -249,6 +250,8 @@ int rph_init(int device, rph_ctx **out)
         }
         RPH_HIP_CHECK(hipSetDevice(device));
         rph_ctx *ctx = new rph_ctx();
+        static std::atomic<uint64_t> next_serial{1};
+        ctx->serial = next_serial.fetch_add(1);
         ctx->device = device;
         ctx->compute_units = prop.multiProcessorCount;
         hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -271,6 +274,7 @@ int rph_shutdown(rph_ctx *ctx)
     rph_pipe_forget(ctx);
     rph_resize_forget(ctx);
     rph_jpeg_forget(ctx);
+    rph_jpeg_forget_threads(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto &kv : ctx->ll_scratch) (void)hipFree(kv.second.p);
     if (ctx->sink) (void)hipFree(ctx->sink);

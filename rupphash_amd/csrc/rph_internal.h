@@ -64,6 +64,8 @@ struct rph_ctx {
     std::condition_variable jpeg_qcv;
     std::vector<void *> jpeg_waiting;
     bool jpeg_leader = false;
+    std::vector<void *> jpeg_thread_buffers;  // the callers' pinned coefficient buffers (one per calling thread), freed with the context
+    uint64_t serial = 0;                      // distinguishes this context from an earlier one at the same address
 };
 
 void rph_set_error(const char *fmt, ...);
@@ -138,6 +140,7 @@ void rph_batcher_forget(rph_ctx *ctx);
 void rph_resize_forget(rph_ctx *ctx);
 // jpeg_kernels.hip
 void rph_jpeg_forget(rph_ctx *ctx);
+void rph_jpeg_forget_threads(rph_ctx *ctx);
 
 // host_grouping.cpp
 int rph_host_union_find(const rph_edge *edges, uint64_t n_edges, uint64_t n, uint32_t *members, uint32_t *offsets,
