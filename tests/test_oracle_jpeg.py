@@ -140,3 +140,32 @@ def test_unsupported_and_corrupt_streams_are_refused_not_crashed_on():
             Engine.jpeg_coefficients(bytes(bad))
         except _lib.RphError:
             pass
+
+
+def test_host_decoder_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """tools/fuzz_jpeg_host.cpp: the host half (jpeg_host.cpp) compiled with ASan + UBSan on the CPU, fed intact files and thousands of
+    damaged variants (overwritten bytes, truncation, inserted bytes, planted markers); any report fails the run"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    k = 0
+    for (w, h), (mode, ss), prog, (q, opt, rst) in itertools.product([(16, 16), (33, 31), (100, 37)], [("RGB", 0), ("RGB", 2), ("L", 0)], [False, True],
+                                                                     [(30, False, 0), (95, True, 0), (75, False, 3)]):
+        kw = dict(quality=q, progressive=prog, optimize=opt)
+        if mode == "RGB":
+            kw["subsampling"] = ss
+        if rst:
+            kw["restart_marker_blocks"] = rst
+        (tmp_path / f"f{k:03d}.jpg").write_bytes(ju.pillow_jpeg(ju.make_image(w, h, mode, seed=k), **kw))
+        k += 1
+    (tmp_path / "g.jpg").write_bytes(ju.encode_baseline(np.array(ju.make_image(40, 56)), ((1, 2), (1, 1), (1, 1)), 1.0, 5, interleaved=False))
+    (tmp_path / "p.jpg").write_bytes(_read("Prophecy_Has_Been_Fulfilled_1.jpg"))
+    exe = str(tmp_path / "fuzz_jpeg_host")
+    try:
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", os.path.join(root, "rupphash_amd", "csrc"),
+                               "-I", os.path.join(root, "include"), os.path.join(root, "tools", "fuzz_jpeg_host.cpp"), os.path.join(root, "rupphash_amd", "csrc", "jpeg_host.cpp"),
+                               "-o", exe])
+    except (subprocess.CalledProcessError, FileNotFoundError):
+        pytest.skip("no sanitizer runtime for g++ here")
+    r = subprocess.run([exe, str(tmp_path), "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "no sanitizer report" in r.stdout, r.stdout + r.stderr[-3000:]
