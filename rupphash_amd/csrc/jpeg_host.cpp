@@ -11,6 +11,9 @@
 #include "jpeg_host.h"
 
 #include <string.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "../../include/rupphash.h"
 
@@ -609,19 +612,61 @@ int build_device_lut(const TableSpec &t, DeviceLut &out)
 }
 
 namespace {
+// 32 bytes per step where the CPU has AVX2 (a 0xFF turns up every ~256 bytes of entropy data, so scanning for it and copying whole
+// runs is what this pass spends its time in), memchr + memcpy otherwise
+#if defined(__x86_64__)
+// copies [p, first 0xFF) to out while looking for it: one pass over the bytes instead of memchr + memcpy
+__attribute__((target("avx2"))) const uint8_t *copy_until_ff_avx2(const uint8_t *p, const uint8_t *end, uint8_t *&out)
+{
+    const __m256i ff = _mm256_set1_epi8((char)0xFF);
+    uint8_t *o = out;
+    while (end - p >= 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)p);
+        const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, ff));
+        _mm256_storeu_si256((__m256i *)o, v);  // (the caller guarantees 32 bytes of slack behind the bytes that count)
+        if (m) {
+            const int k = __builtin_ctz(m);
+            out = o + k;
+            return p + k;
+        }
+        p += 32;
+        o += 32;
+    }
+    while (p < end && *p != 0xFF) *o++ = *p++;
+    out = o;
+    return p;
+}
+#endif
+
 // entropy bytes of one scan, byte stuffing undone and RSTn dropped; returns the position of the marker that ends the scan
 const uint8_t *destuff(const uint8_t *p, const uint8_t *end, uint8_t *&out, uint8_t *out_end)
 {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+#endif
     while (p < end) {
-        const uint8_t *q = (const uint8_t *)memchr(p, 0xFF, (size_t)(end - p));
-        const size_t run = (size_t)((q ? q : end) - p);
-        if ((size_t)(out_end - out) < run + 1) return nullptr;
-        memcpy(out, p, run);
-        out += run;
-        if (!q) return end;
+        const uint8_t *q;
+#if defined(__x86_64__)
+        if (avx2) {
+            // the output never gets ahead of the input (bytes are only ever dropped), and the buffer holds len + 160 bytes: 32 bytes of
+            // slack for the whole-vector stores are there as long as 64 bytes remain for the scan's padding, checked here
+            if ((size_t)(out_end - out) < (size_t)(end - p) + 64) return nullptr;
+            q = copy_until_ff_avx2(p, end, out);
+        } else
+#endif
+        {
+            const uint8_t *f = (const uint8_t *)memchr(p, 0xFF, (size_t)(end - p));
+            q = f ? f : end;
+            const size_t run = (size_t)(q - p);
+            if ((size_t)(out_end - out) < run + 1) return nullptr;
+            memcpy(out, p, run);
+            out += run;
+        }
+        if (q >= end) return end;
         if (q + 1 >= end) return q;
         const uint8_t m = q[1];
         if (m == 0x00) {
+            if (out >= out_end) return nullptr;
             *out++ = 0xFF;
             p = q + 2;
         } else if (m >= 0xD0 && m <= 0xD7) {
