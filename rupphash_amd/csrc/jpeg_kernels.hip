@@ -717,10 +717,10 @@ struct Job {
 
 using Jobs = std::vector<Job>;
 
-// Channels of the pixels the device writes for a file: Rgb8 only where someone reads RGB -- the caller (rph_jpeg_decode) or the fused
-// 512x512 RGB kernel; every other colour file is hashed from its Rec.601 luma, written directly (a third of the bytes, and the PDQ
-// paths start from luma anyway: Luma8 input is borrowed as it is, pdqhash.rs:176)
-inline uint32_t out_channels(const rphj::Frame &f, bool rgb_wanted) { return f.ncomp == 1 ? 1u : ((rgb_wanted || (f.w == 512 && f.h == 512)) ? 3u : 1u); }
+// Channels of the pixels the device writes for a file: Rgb8 only where the caller reads RGB (rph_jpeg_decode); a colour file that
+// only the hasher reads is written as its Rec.601 luma (a third of the bytes, and the PDQ paths start from luma anyway: Luma8 input
+// is borrowed as it is, pdqhash.rs:176; 512x512 Luma8 has its own form of the fused kernel)
+inline uint32_t out_channels(const rphj::Frame &f, bool rgb_wanted) { return (f.ncomp == 1 || !rgb_wanted) ? 1u : 3u; }
 
 size_t out_bytes_of(const rphj::Frame &f, uint32_t channels)
 {

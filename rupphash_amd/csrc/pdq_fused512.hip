@@ -38,9 +38,10 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 //             line is requested by two tiles (L2->fabric traffic 1.30 x algorithmic, profiles/r01_pmc_summary.txt)
 //   SW = 128: 4 strips, tile 64x128 built as two 32-row halves, 26.1 KB LDS -> 6 waves per CU; a strip row is 384 B =
 //             exactly 3 lines, traffic 1.11 x algorithmic (the rest is the edge pre-pass)
-template <int SW_>
+template <int SW_, int CH_ = 3>
 struct Geo {
     static constexpr int SW = SW_;                       // strip width in pixels
+    static constexpr int CH = CH_;                       // 3 = Rgb8 input, 1 = Luma8 input (the reference borrows a Luma8 image as it is, pdqhash.rs:176)
     static constexpr int NSTRIP = 512 / SW;
     static constexpr int CL = SW / 8;                    // lanes across a strip row, 8 px each
     static constexpr int NG = 64 / CL;                   // lane groups of 8 rows -> NG * 8 rows per build step
@@ -68,11 +69,20 @@ struct __attribute__((packed, aligned(4))) U3 {
     uint32_t x, y, z;
 };
 
+struct __attribute__((packed, aligned(4))) U2 {
+    uint32_t x, y;
+};
+template <int CH = 3>
 __device__ __forceinline__ Px8 load_px8(const uint8_t *p)
 {
+    Px8 r;
+    if (CH == 1) {  // 8 luma bytes: d[0], d[1]
+        const U2 a = *reinterpret_cast<const U2 *>(p);
+        r.d[0] = a.x; r.d[1] = a.y; r.d[2] = r.d[3] = r.d[4] = r.d[5] = 0;
+        return r;
+    }
     const U3 a = *reinterpret_cast<const U3 *>(p);
     const U3 b = *reinterpret_cast<const U3 *>(p + 12);
-    Px8 r;
     r.d[0] = a.x; r.d[1] = a.y; r.d[2] = a.z; r.d[3] = b.x; r.d[4] = b.y; r.d[5] = b.z;
     return r;
 }
@@ -91,8 +101,14 @@ __device__ __forceinline__ float luma_px(const Px8 &v)
     return __builtin_truncf(num * 0.001f);
 }
 
+template <int CH = 3>
 __device__ __forceinline__ void luma8(const Px8 &v, float (&l)[8])
 {
+    if (CH == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) l[i] = (float)((v.d[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+        return;
+    }
     l[0] = luma_px<0>(v); l[1] = luma_px<1>(v); l[2] = luma_px<2>(v); l[3] = luma_px<3>(v);
     l[4] = luma_px<4>(v); l[5] = luma_px<5>(v); l[6] = luma_px<6>(v); l[7] = luma_px<7>(v);
 }
@@ -165,7 +181,27 @@ __device__ __forceinline__ Row8 luma_row(const Pairs12 &pr, bool zero, uint32_t 
     }
     return r;
 }
-__device__ __forceinline__ Row8 pack_row(const Px8 &v, bool zero, uint32_t &order) { return luma_row(byte_pairs(v), zero, order); }
+// Luma8 input: the bytes are the luma; pairs of them become f16 (1024 + v) by the same v_perm, and the bias leaves exactly
+__device__ __forceinline__ Row8 luma_row_gray(const Px8 &v, bool zero, uint32_t &order)
+{
+    const h2 bias = h2{(_Float16)1024.0f, (_Float16)1024.0f};
+    Row8 r;
+    r.q[0] = byte_pair_lo(v.d[0]) - bias;
+    r.q[1] = byte_pair_hi(v.d[0]) - bias;
+    r.q[2] = byte_pair_lo(v.d[1]) - bias;
+    r.q[3] = byte_pair_hi(v.d[1]) - bias;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (zero) r.q[i] = h2{(_Float16)0, (_Float16)0};
+    order = __builtin_bit_cast(uint32_t, r.q[3]);
+    return r;
+}
+template <int CH = 3>
+__device__ __forceinline__ Row8 pack_row(const Px8 &v, bool zero, uint32_t &order)
+{
+    if (CH == 1) return luma_row_gray(v, zero, order);
+    return luma_row(byte_pairs(v), zero, order);
+}
 __device__ __forceinline__ uint4 row_bits(const Row8 &r)
 {
     uint4 u;
@@ -238,11 +274,12 @@ template <class G>
 __device__ __forceinline__ void half_offsets(const Wave &w, int b, int s, int h, uint32_t &off0, uint32_t &off_max)
 {
     const int c = w.lane & (G::CL - 1), g = w.lane / G::CL;
-    const uint32_t col = (uint32_t)(G::SW * s + 8 * c) * 3u;
+    const uint32_t col = (uint32_t)(G::SW * s + 8 * c) * (uint32_t)G::CH;
     off0 = (uint32_t)half_row<G>(b, h, g, 0) * w.rs32 + col;
     off_max = 511u * w.rs32 + col;
 }
-__device__ __forceinline__ Px8 load_px8_at(const Wave &w, uint32_t off) { return load_px8(w.img + off); }  // uniform base + 32-bit lane offset
+template <int CH>
+__device__ __forceinline__ Px8 load_px8_at(const Wave &w, uint32_t off) { return load_px8<CH>(w.img + off); }  // uniform base + 32-bit lane offset
 
 // LOAD phase 1 (only for the very first tile of the image): issue the 16 loads of half tile (b, s, h)
 template <class G>
@@ -252,7 +289,7 @@ __device__ __forceinline__ void half_issue(const Wave &w, int b, int s, int h, P
     half_offsets<G>(w, b, s, h, off, off_max);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        pre[k] = load_px8_at(w, off);
+        pre[k] = load_px8_at<G::CH>(w, off);
         off = off + w.rs32;
         off = off < off_max ? off : off_max;
     }
@@ -269,8 +306,16 @@ __device__ __forceinline__ void half_luma(const Wave &w, int b, int h, Px8 (&pre
     uint32_t order = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
+        if (G::CH == 1) {
+            const Px8 cur = pre[k];
+            if (has_next) pre[k] = load_px8_at<1>(w, off);
+            off = off + w.rs32;
+            off = off < off_max ? off : off_max;
+            L[k] = luma_row_gray(cur, LAST_BAND && (half_row<G>(b, h, g, k) >= 512), order);
+            continue;
+        }
         const Pairs12 pr = byte_pairs(pre[k]);
-        if (has_next) pre[k] = load_px8_at(w, off);
+        if (has_next) pre[k] = load_px8_at<3>(w, off);
         off = off + w.rs32;
         off = off < off_max ? off : off_max;
         L[k] = luma_row(pr, LAST_BAND && (half_row<G>(b, h, g, k) >= 512), order);
@@ -483,16 +528,17 @@ __device__ __forceinline__ void col_pass(Wave &w, int b, bool second_half)
 
 // edge pre-pass: pass-1 values (x64) of columns 0,1,2,508,509,510 for V rows 64b .. 64b+63
 //   (FIRST: also consumes the chain's phase 1 = luma rows 0..3)
+template <int CH>
 __device__ __forceinline__ void edge_rowvals(const Wave &w, int y, bool live, float (&rv)[6])
 {
     // lane = luma row y: R = horizontal clipped window sum of luma (exact), rowval x 64 = (64 R) / window; the numerators are
     // multiples of 64 below 2^17 and the divisors 5, 6, 7, so div_small gives the IEEE quotient
     const int yc = y > 511 ? 511 : y;
-    const Px8 pl = load_px8(w.img + (size_t)yc * w.row_stride);
-    const Px8 pr = load_px8(w.img + (size_t)yc * w.row_stride + 504 * 3);
+    const Px8 pl = load_px8<CH>(w.img + (size_t)yc * w.row_stride);
+    const Px8 pr = load_px8<CH>(w.img + (size_t)yc * w.row_stride + 504 * CH);
     float l[8], r[8];
-    luma8(pl, l);
-    luma8(pr, r);
+    luma8<CH>(pl, l);
+    luma8<CH>(pr, r);
     const float r0 = (((l[0] + l[1]) + l[2]) + l[3]) + l[4];
     const float r1 = r0 + l[5];
     const float r2 = r1 + l[6];
@@ -516,7 +562,7 @@ __device__ __forceinline__ void edge_prologue(Wave &w)
 {
     float *edge = reinterpret_cast<float *>(w.lds + G::OFF_EDGE);
     float rv[6];
-    edge_rowvals(w, w.lane & 3, true, rv);
+    edge_rowvals<G::CH>(w, w.lane & 3, true, rv);
     if (w.lane < 4) {
 #pragma unroll
         for (int k = 0; k < 6; k++) edge[k * 64 + w.lane] = rv[k];
@@ -543,7 +589,7 @@ __device__ __forceinline__ void edge_band(Wave &w, int b)
     {
         float rv[6];
         const int y = 64 * b + 4 + w.lane;
-        edge_rowvals(w, y, y < 512, rv);
+        edge_rowvals<G::CH>(w, y, y < 512, rv);
 #pragma unroll
         for (int k = 0; k < 6; k++) edge[k * 64 + w.lane] = rv[k];
     }
@@ -677,8 +723,8 @@ __global__ void __launch_bounds__(64, G::WAVES_PER_SIMD) pdq_fused512_kernel(con
         for (int it = 0; it < 4; it++) {
             const int slot = it * 64 + w.lane;
             const int chunk = slot & 63, row = slot >> 6;
-            const Px8 p = load_px8(w.img + (size_t)row * row_stride + (size_t)(8 * chunk) * 3);
-            *reinterpret_cast<uint4 *>(lds + G::OFF_STATE + (3 + row) * 1024 + (8 * chunk) * 2) = row_bits(pack_row(p, false, order));
+            const Px8 p = load_px8<G::CH>(w.img + (size_t)row * row_stride + (size_t)(8 * chunk) * G::CH);
+            *reinterpret_cast<uint4 *>(lds + G::OFF_STATE + (3 + row) * 1024 + (8 * chunk) * 2) = row_bits(pack_row<G::CH>(p, false, order));
         }
     }
     edge_prologue<G>(w);
@@ -749,7 +795,7 @@ __global__ void __launch_bounds__(512, 2) pdq_fused512_ll_kernel(const uint8_t *
     // ---- chain inputs of this band's rows (the chains' phase-1 rows 0..3 are ordinary inputs here)
     {
         float rv[6];
-        edge_rowvals(w, 64 * band + w.lane, true, rv);
+        edge_rowvals<G::CH>(w, 64 * band + w.lane, true, rv);
 #pragma unroll
         for (int k = 0; k < 6; k++) edge_all[k * LL_EDGE_PITCH + 64 * band + w.lane] = rv[k];
         if (band == 7 && w.lane < 8) {
@@ -764,7 +810,7 @@ __global__ void __launch_bounds__(512, 2) pdq_fused512_ll_kernel(const uint8_t *
         for (int it = 0; it < 7; it++) {
             const int row = 64 * band - 3 + it;  // state row `it`; every lane takes one 8-px chunk
             uint4 bits = make_uint4(0, 0, 0, 0);
-            if (row >= 0) bits = row_bits(pack_row(load_px8(w.img + (size_t)row * row_stride + (size_t)(8 * w.lane) * 3), false, order));
+            if (row >= 0) bits = row_bits(pack_row<G::CH>(load_px8<G::CH>(w.img + (size_t)row * row_stride + (size_t)(8 * w.lane) * G::CH), false, order));
             *reinterpret_cast<uint4 *>(w.lds + G::OFF_STATE + it * 1024 + (8 * w.lane) * 2) = bits;
         }
     }
@@ -899,9 +945,15 @@ int rph_launch_pdq_fused512_ll(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, si
 
 int rph_launch_pdq_fused512(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, size_t row_stride, size_t image_stride,
                             uint8_t *d_hash, float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid,
-                            hipStream_t stream)
+                            hipStream_t stream, uint32_t channels)
 {
     if (n == 0) return RPH_OK;
+    if (channels == 1) {  // Luma8: the one-wave-per-image kernel at every batch size (a third of the bytes, no luma arithmetic)
+        hipLaunchKernelGGL((pdq_fused512_kernel<Geo<64, 1>>), dim3(n), dim3(64), 0, stream, d_px, n, row_stride, image_stride, d_hash, d_quality, d_coeffs, d_dihedral,
+                           d_valid);
+        RPH_HIP_CHECK(hipGetLastError());
+        return RPH_OK;
+    }
     // 3 = the low-latency kernel, 4 (default) = automatic: below ~3 images per CU the eight-waves-per-image kernel finishes sooner
     // (~60 us against ~300 us), above it the one-wave-per-image kernel has the throughput
     if (ctx->pdq_kernel == 3 || (ctx->pdq_kernel == 4 && n < 768))

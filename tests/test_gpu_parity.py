@@ -481,6 +481,33 @@ def test_fused512_kernel_matches_oracle_bit_for_bit(eng, oracle, which):
         assert np.array_equal(out["dihedral"][k], oracle.dihedral_hashes(coeffs)), k
 
 
+def test_fused512_luma8_input_matches_oracle_and_generic_kernels(eng, oracle):
+    """512x512 Luma8 (the reference borrows a Luma8 image as it is, pdqhash.rs:176): the fused kernel's Luma8 form against the oracle on the
+    adversarial set (one channel of each image, and its Rec.601 luma), and against the generic kernels on 2000 random gray images"""
+    rgb = _fused_images()
+    gray = np.concatenate([rgb[..., 1], oracle.luma601(rgb[0])[None], oracle.luma601(rgb[-1])[None]])
+    out = eng.pdq_hash_batch(gray, want_quality=True, want_coeffs=True, want_dihedral=True)
+    for k in range(len(gray)):
+        rc, coeffs, q = oracle.pdq_features(gray[k])
+        assert rc == 0 and out["valid"][k] == 1
+        assert np.array_equal(bits(out["coeffs"][k]), bits(coeffs)), f"coefficients differ for gray image {k}"
+        assert bits(out["quality"][k:k + 1])[0] == bits(np.float32(q))[()], k
+        assert np.array_equal(out["hash"][k], oracle.to_hash(coeffs)) and np.array_equal(out["dihedral"][k], oracle.dihedral_hashes(coeffs)), k
+    # a Luma8 image hashes like the gray Rgb8 image r = g = b (luma601 of equal channels is the channel: (1000 v + 500) / 1000)
+    k = 3
+    same = eng.pdq_hash_batch(np.repeat(gray[k][None, :, :, None], 3, axis=3), want_coeffs=True)
+    assert np.array_equal(bits(same["coeffs"][0]), bits(out["coeffs"][k]))
+    rng = np.random.default_rng(5)
+    many = rng.integers(0, 256, (2000, 512, 512), dtype=np.uint8)
+    many[::3] = (many[::3] >> 5) * 30  # coarse levels: ties
+    fused = eng.pdq_hash_batch(many, want_quality=True, want_coeffs=True)
+    eng.set_pdq_kernel(0)
+    generic = eng.pdq_hash_batch(many, want_quality=True, want_coeffs=True)
+    eng.set_pdq_kernel(4)
+    assert np.array_equal(fused["hash"], generic["hash"]) and np.array_equal(bits(fused["coeffs"]), bits(generic["coeffs"]))
+    assert np.array_equal(bits(fused["quality"]), bits(generic["quality"]))
+
+
 @pytest.mark.parametrize("which", [1, 2, 3])
 def test_fused512_on_synthetic_bench_images(eng, oracle, which):
     """the bench workload itself: 24 images of the synthetic sequence (incl. a near-duplicate pair) vs the oracle"""
