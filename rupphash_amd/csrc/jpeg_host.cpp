@@ -639,8 +639,9 @@ __attribute__((target("avx2"))) const uint8_t *copy_until_ff_avx2(const uint8_t 
 #endif
 
 // entropy bytes of one scan, byte stuffing undone and RSTn dropped; returns the position of the marker that ends the scan
-const uint8_t *destuff(const uint8_t *p, const uint8_t *end, uint8_t *&out, uint8_t *out_end)
+const uint8_t *destuff(const uint8_t *p, const uint8_t *end, uint8_t *&out, uint8_t *out_end, std::vector<uint32_t> *marks)
 {
+    const uint8_t *const scan_out = out;
 #if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2");
 #endif
@@ -671,6 +672,7 @@ const uint8_t *destuff(const uint8_t *p, const uint8_t *end, uint8_t *&out, uint
             p = q + 2;
         } else if (m >= 0xD0 && m <= 0xD7) {
             p = q + 2;  // restart marker: the decoder counts MCUs
+            if (marks) marks->push_back((uint32_t)(out - scan_out));
         } else if (m == 0xFF) {
             p = q + 1;  // fill byte
         } else {
@@ -681,8 +683,10 @@ const uint8_t *destuff(const uint8_t *p, const uint8_t *end, uint8_t *&out, uint
 }
 }  // namespace
 
-int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used, InternTable intern, void *store)
+int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used, InternTable intern, void *store,
+                   std::vector<uint32_t> *restart_marks)
 {
+    if (restart_marks) restart_marks->clear();
     if (!f.have_sof || f.progressive) return RPH_ERR_UNSUPPORTED;
     plan = StreamPlan();
     TableSpec dc[4], ac[4];
@@ -774,7 +778,8 @@ int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, 
             }
             sc.restart_interval = f.restart_interval;
             sc.stream_off = (uint32_t)(o - out);
-            const uint8_t *stop = destuff(data + pos, data + len, o, o_end);
+            const bool mark = restart_marks && plan.n_scans == 0 && f.restart_interval != 0;
+            const uint8_t *stop = destuff(data + pos, data + len, o, o_end, mark ? restart_marks : nullptr);
             if (!stop || (size_t)(o_end - o) < 32) return RPH_ERR_CAPACITY;
             sc.stream_len = (uint32_t)(o - out) - sc.stream_off;
             memset(o, 0, 32);
@@ -790,6 +795,13 @@ int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, 
     if (f.ncomp == 3 && f.adobe_transform == 0) return RPH_ERR_UNSUPPORTED;
     for (int c = 0; c < f.ncomp; c++)
         if (!f.qt_present[f.comp[c].tq]) return RPH_ERR_INVALID_ARG;
+    if (restart_marks && !restart_marks->empty()) {
+        // usable only if the file is one scan and the marks are exactly the interval boundaries
+        const ScanPlan &sc = plan.scan[0];
+        const uint64_t mcus = sc.ns == 1 ? (uint64_t)f.comp[sc.ci[0]].real_bw * f.comp[sc.ci[0]].real_bh : (uint64_t)f.mcus_x * f.mcus_y;
+        const uint64_t intervals = sc.restart_interval ? (mcus + sc.restart_interval - 1) / sc.restart_interval : 0;
+        if (plan.n_scans != 1 || intervals == 0 || restart_marks->size() + 1 != intervals) restart_marks->clear();
+    }
     *used = (size_t)(o - out);
     return RPH_OK;
 }

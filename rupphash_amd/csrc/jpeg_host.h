@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace rphj {
 
 struct Comp {
@@ -75,7 +77,11 @@ typedef uint32_t (*InternTable)(void *store, const TableSpec &t);
 // bytes of each scan to `out` with the byte stuffing undone (0xFF00 -> 0xFF) and the RSTn markers dropped (the decoder byte-aligns
 // every restart_interval MCUs instead), 32 zero bytes after each scan; at most `cap` bytes (len + 160 always suffices).
 // RPH_ERR_UNSUPPORTED: progressive, or more than 4 scans -- the caller uses decode_coefficients for that file.
-int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used, InternTable intern, void *store);
+// `restart_marks` (nullable): for a file of ONE scan with a restart interval, the offsets (from the scan's first byte in `out`) at which
+// the restart intervals after the first begin -- every interval is an independent bit stream (predictions reset, byte aligned), so
+// the device can give each a lane of its own.  Left empty when the marks do not add up to ceil(MCUs / interval) - 1.
+int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, uint8_t *out, size_t cap, size_t *used, InternTable intern, void *store,
+                   std::vector<uint32_t> *restart_marks = nullptr);
 int build_device_lut(const TableSpec &t, DeviceLut &out);
 
 }  // namespace rphj

@@ -366,6 +366,15 @@ struct HImage {
     HScan scan[4];
 };
 
+// One lane's work: a whole image (scan == HITEM_ALL_SCANS: its scans one after the other, restart intervals handled in the walk), or ONE
+// restart interval of a single-scan image: mcu_count MCUs from mcu_first, whose bits begin stream_off bytes into the scan -- every
+// restart interval is an independent stream (predictions reset, byte aligned), so a file with restart markers is walked by as many
+// lanes as it has intervals.
+constexpr uint32_t HITEM_ALL_SCANS = 0xFFFFFFFFu;
+struct HItem {
+    uint32_t image, scan, mcu_first, mcu_count, stream_off;
+};
+
 __constant__ uint8_t c_zigzag[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
                                      6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
                                      39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
@@ -385,8 +394,9 @@ __device__ __forceinline__ T sel3(uint32_t i, T a, T b, T c)
 // time of a cached global read.
 constexpr int HUFF_LDS_TABLES = 8;
 template <int LDS_TABLES>
-__global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const uint32_t *__restrict__ order, uint32_t n,
-                                                       const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts, int16_t *__restrict__ coef, uint8_t *__restrict__ status)
+__global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const HItem *__restrict__ items,
+                                                       const uint32_t *__restrict__ order, uint32_t n, const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts,
+                                                       int16_t *__restrict__ coef, uint8_t *__restrict__ status)
 {
     __shared__ uint8_t zz[80];
     __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
@@ -401,14 +411,16 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
     __syncthreads();
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
     if (slot >= n) return;
-    const uint32_t ii = order[slot];
+    const HItem item = items[order[slot]];
+    const uint32_t ii = item.image;
     const HImage *im = imgs + ii;
     const uint64_t img_fb = im->first_block;
     uint32_t bad = 0;
-    const uint32_t n_scans = im->n_scans;
-    for (uint32_t sc = 0; sc < n_scans && !bad; sc++) {
+    const bool part = item.scan != HITEM_ALL_SCANS;  // one restart interval of the image's only scan
+    const uint32_t sc_end = part ? item.scan + 1 : im->n_scans;
+    for (uint32_t sc = part ? item.scan : 0; sc < sc_end && !bad; sc++) {
         const HScan *S = &im->scan[sc];
-        const uint32_t ns = S->ns, ri = S->restart_interval;
+        const uint32_t ns = S->ns, ri = part ? 0 : S->restart_interval;
         // the scan's components (scan order); a single-component scan walks the component's own block grid (T.81 A.2.2)
         uint32_t H0, H1, H2, V0, V1, V2, BW0, BW1, BW2, FB0, FB1, FB2;
         const rphj::DeviceLut *D0, *D1, *D2, *A0, *A1, *A2;
@@ -423,10 +435,11 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
         }
         const uint32_t MX = ns == 1 ? im->comp[S->ci[0]].real_bw : im->mcus_x, MY = ns == 1 ? im->comp[S->ci[0]].real_bh : im->mcus_y;
         const uint32_t per_mcu = H0 * V0 + (ns > 1 ? H1 * V1 : 0) + (ns > 2 ? H2 * V2 : 0);
-        const uint64_t max_it = (uint64_t)MX * MY * per_mcu * 65 + 8;  // a block takes at most 1 + 63 symbols: the walk always ends
+        const uint64_t max_it = (part ? (uint64_t)item.mcu_count : (uint64_t)MX * MY) * per_mcu * 65 + 8;  // a block takes at most 1 + 63 symbols: the walk always ends
         // bit reader: `off` bytes of the scan consumed into acc (MSB first), nb valid bits
-        const uint8_t *sp = streams + im->stream_base + S->off;
-        const uint32_t slen = S->len;
+        const uint32_t skip = part ? item.stream_off : 0;
+        const uint8_t *sp = streams + im->stream_base + S->off + skip;
+        const uint32_t slen = S->len - (skip < S->len ? skip : S->len);
         // acc: the next bits, MSB first, nb of them valid.  Behind it two 8-byte words: q0 ready, q1 in flight (loaded one word ahead, so a
         // refill never waits for memory), each fetched with ONE load instruction from a 4-byte-aligned address: the per-CU address unit,
         // which takes a fully divergent wave access lane by lane, is what bounds this kernel, so loads per symbol are what matters.
@@ -441,12 +454,13 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
         W2 q1 = load8(12);  // kept as loaded: its bytes are swapped when it becomes q0, a word later, so nothing waits on the load now
         uint32_t q0n = 64, woff = 20;
         // position: component i of the MCU, block (h, v) of the component, MCU (mx, my); k = next coefficient index (zigzag order)
-        uint32_t i = 0, h = 0, v = 0, mx = 0, my = 0, k = 0, until = ri;
+        const uint32_t m0 = part && MX ? item.mcu_first : 0;
+        uint32_t i = 0, h = 0, v = 0, mx = MX ? m0 % MX : 0, my = MX ? m0 / MX : 0, k = 0, until = ri, left = part ? item.mcu_count : 0xFFFFFFFFu;
         uint32_t Hc = H0, Vc = V0, BWc = BW0, FBc = FB0;
         const rphj::DeviceLut *DCc = D0, *ACc = A0;
         int p0 = 0, p1 = 0, p2 = 0;
-        bool is_dc = true, done = MX == 0 || MY == 0;
-        uint64_t base = (img_fb + FBc) * 64;
+        bool is_dc = true, done = MX == 0 || MY == 0 || my >= MY || left == 0;
+        uint64_t base = (img_fb + FBc + (uint64_t)(my * Vc) * BWc + mx * Hc) * 64;
         for (uint64_t it = 0; !done && it < max_it; it++) {
             if (nb < 32) {  // 4 more bytes
                 acc |= (q0 >> 32) << (32 - nb);
@@ -526,6 +540,7 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
                                 mx = 0;
                                 if (++my == MY) done = true;
                             }
+                            if (--left == 0) done = true;
                         }
                         Hc = sel3(i, H0, H1, H2);
                         Vc = sel3(i, V0, V1, V2);
@@ -540,7 +555,7 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
         }
         if (!done) bad = 1;
     }
-    status[ii] = (uint8_t)bad;
+    if (bad) status[ii] = 1;  // (the results were zeroed before the launch; several lanes may share an image)
 }
 
 #define RPH_TRY(expr)                  \
@@ -712,6 +727,7 @@ struct Job {
     uint64_t first_block = 0;  // within the chunk's coefficient buffer
     rphj::StreamPlan plan;     // device entropy
     const int16_t *pre = nullptr;  // coefficients already decoded by the caller into pinned memory (rph_jpeg_pdq_hash_one)
+    std::vector<uint32_t> marks;   // device entropy: where the restart intervals of a one-scan file begin (empty: walk the file with one lane)
     size_t stream_off = 0, stream_used = 0;
 };
 
@@ -1079,8 +1095,12 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     // The walk of a chunk takes as long as its longest file (~0.65 us per entropy byte: 21 ms for 29 KB files, 236 ms for 366 KB photos)
     // however few files it has, and walks of different chunks only overlap pairwise (two lanes): small files are cut into four chunks
     // for the pipelining, photo-sized files into two so that the walks are not paid four times.
-    size_t max_len = 0;
-    for (uint32_t g : idx) max_len = std::max(max_len, jobs[g].len);
+    size_t max_len = 0;  // longest stream one lane will walk: a file, or one restart interval of it (as the frame header announces them)
+    for (uint32_t g : idx) {
+        const rphj::Frame &f = jobs[g].frame;
+        const uint64_t mcus = (uint64_t)f.mcus_x * f.mcus_y, intervals = f.restart_interval ? (mcus + f.restart_interval - 1) / f.restart_interval : 1;
+        max_len = std::max(max_len, jobs[g].len / (size_t)std::max<uint64_t>(1, intervals));
+    }
     size_t min_chunk = (size_t)16 << 30, parts = 0.65e-6 * (double)max_len > 0.08 ? 2 : 4;
     if (const char *e = getenv("RPH_JPEG_CHUNK_GB")) min_chunk = (size_t)atoi(e) << 30;  // experiments
     if (const char *e = getenv("RPH_JPEG_PARTS")) parts = (size_t)atoi(e);
@@ -1166,7 +1186,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             Job &j = jobs[idx[i]];
             HImage &hi = himgs[i - first];
             memset(&hi, 0, sizeof hi);
-            j.status = rphj::prepare_stream(j.data, j.len, j.frame, j.plan, S.stream_bytes.h + j.stream_off, align_up(j.len + 160, 16), &j.stream_used, &TableStore::intern, &store);
+            j.status = rphj::prepare_stream(j.data, j.len, j.frame, j.plan, S.stream_bytes.h + j.stream_off, align_up(j.len + 160, 16), &j.stream_used, &TableStore::intern, &store, &j.marks);
             if (j.status != RPH_OK) return;
             const rphj::Frame &f = j.frame;
             hi.first_block = j.first_block;
@@ -1195,24 +1215,46 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         });
         const double t_prep = now_ms();
         RPH_JPEG_STAMP("lane %d: chunk %d prepared (%zu files)", b, k, m);
-        // files the walk does not take (more than four scans) go back to the host decoder; they keep their place in the chunk as holes
-        std::vector<uint32_t> order;
-        order.reserve(m);
+        // files the walk does not take (more than four scans) go back to the host decoder; they keep their place in the chunk as holes.
+        // Work items: one per restart interval where a file has them, else one per file; lanes take them longest first.
+        std::vector<HItem> items;
+        std::vector<uint32_t> item_len;
+        items.reserve(m);
         for (size_t i = first; i < last; i++) {
             Job &j = jobs[idx[i]];
             if (j.status == RPH_ERR_UNSUPPORTED || j.status == RPH_ERR_CAPACITY) leftover.push_back(idx[i]);
-            if (j.status == RPH_OK) order.push_back((uint32_t)(i - first));
+            if (j.status != RPH_OK) continue;
+            const uint32_t r = (uint32_t)(i - first);
+            if (j.marks.empty()) {
+                items.push_back(HItem{r, HITEM_ALL_SCANS, 0, 0, 0});
+                item_len.push_back((uint32_t)std::min<size_t>(j.len, 0xFFFFFFFFu));
+                continue;
+            }
+            const rphj::ScanPlan &sp = j.plan.scan[0];
+            const rphj::Frame &f = j.frame;
+            const uint64_t mcus = sp.ns == 1 ? (uint64_t)f.comp[sp.ci[0]].real_bw * f.comp[sp.ci[0]].real_bh : (uint64_t)f.mcus_x * f.mcus_y;
+            const uint32_t n_int = (uint32_t)j.marks.size() + 1;
+            for (uint32_t k = 0; k < n_int; k++) {
+                const uint32_t off = k ? j.marks[k - 1] : 0, end = k + 1 < n_int ? j.marks[k] : sp.stream_len;
+                const uint64_t m_first = (uint64_t)k * sp.restart_interval;
+                items.push_back(HItem{r, 0, (uint32_t)m_first, (uint32_t)std::min<uint64_t>(sp.restart_interval, mcus - m_first), off});
+                item_len.push_back(end > off ? end - off : 0);
+            }
         }
+        std::vector<uint32_t> order(items.size());
+        for (uint32_t t = 0; t < order.size(); t++) order[t] = t;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return item_len[a] > item_len[b]; });
         const std::vector<rphj::DeviceLut> &luts = store.luts;
         // ---- meta buffer: reconstruction descriptors | HImage | order | tables
         const size_t recon_bytes = m * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128);
-        const size_t off_himg = align_up(recon_bytes, 16), off_order = off_himg + m * sizeof(HImage), off_luts = align_up(off_order + m * 4, 16),
-                     meta_bytes = off_luts + luts.size() * sizeof(rphj::DeviceLut);
+        const size_t off_himg = align_up(recon_bytes, 16), off_items = off_himg + m * sizeof(HImage), off_order = off_items + items.size() * sizeof(HItem),
+                     off_luts = align_up(off_order + order.size() * 4, 16), meta_bytes = off_luts + luts.size() * sizeof(rphj::DeviceLut);
         RPH_TRY(S.meta.reserve(meta_bytes));
         ChunkDesc D;
         std::vector<size_t> subs;
         RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, false, P.recon_coef_bytes[b], S.meta.h, 0, D, subs));
         memcpy(S.meta.h + off_himg, himgs.data(), m * sizeof(HImage));
+        memcpy(S.meta.h + off_items, items.data(), items.size() * sizeof(HItem));
         memcpy(S.meta.h + off_order, order.data(), order.size() * 4);
         if (!luts.empty()) memcpy(S.meta.h + off_luts, luts.data(), luts.size() * sizeof(rphj::DeviceLut));
         // ---- device: streams up, zeroed coefficients, the walk, then reconstruction + hashing sub-batch by sub-batch
@@ -1236,13 +1278,14 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             {
                 const dim3 grid(((uint32_t)order.size() + 63) / 64);
                 const HImage *d_himg = reinterpret_cast<const HImage *>(S.meta.d + off_himg);
+                const HItem *d_items = reinterpret_cast<const HItem *>(S.meta.d + off_items);
                 const uint32_t *d_order = reinterpret_cast<const uint32_t *>(S.meta.d + off_order);
                 const rphj::DeviceLut *d_luts = reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts);
                 if (luts.size() <= (size_t)HUFF_LDS_TABLES)
-                    hipLaunchKernelGGL(jpeg_huff_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, s, S.stream_bytes.d, d_himg, d_order, (uint32_t)order.size(), d_luts, (uint32_t)luts.size(),
+                    hipLaunchKernelGGL(jpeg_huff_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, s, S.stream_bytes.d, d_himg, d_items, d_order, (uint32_t)order.size(), d_luts, (uint32_t)luts.size(),
                                        d_coef, R.status);
                 else
-                    hipLaunchKernelGGL(jpeg_huff_kernel<0>, grid, dim3(64), 0, s, S.stream_bytes.d, d_himg, d_order, (uint32_t)order.size(), d_luts, (uint32_t)luts.size(), d_coef,
+                    hipLaunchKernelGGL(jpeg_huff_kernel<0>, grid, dim3(64), 0, s, S.stream_bytes.d, d_himg, d_items, d_order, (uint32_t)order.size(), d_luts, (uint32_t)luts.size(), d_coef,
                                        R.status);
             }
             RPH_HIP_CHECK(hipGetLastError());
@@ -1253,9 +1296,9 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             }
             lap(t_rec);
             if (tr)
-                fprintf(stderr, "[rph_jpeg] chunk of %zu files (%.1f MB of entropy bytes, %.2f GB of coefficients, %zu tables, %zu sub-batches): prepare %.1f ms, "
+                fprintf(stderr, "[rph_jpeg] chunk of %zu files in %zu lanes (%.1f MB of entropy bytes, %.2f GB of coefficients, %zu tables, %zu sub-batches): prepare %.1f ms, "
                                 "descriptors %.1f ms, upload %.1f ms, zero %.1f ms, walk %.1f ms, reconstruct + hash %.1f ms\n",
-                        m, file_bytes / 1e6, blocks * 128 / 1e9, luts.size(), subs.size(), t_prep - t0, t_desc - t_prep, t_up - t_desc, t_zero - t_up, t_walk - t_zero, t_rec - t_walk);
+                        m, order.size(), file_bytes / 1e6, blocks * 128 / 1e9, luts.size(), subs.size(), t_prep - t0, t_desc - t_prep, t_up - t_desc, t_zero - t_up, t_walk - t_zero, t_rec - t_walk);
         }
         RPH_HIP_CHECK(hipEventRecord(S.done, s));
         RPH_JPEG_STAMP("lane %d: chunk %d enqueued", b, k);
