@@ -371,7 +371,8 @@ int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int fla
  *   RPH_JPEG_ENTROPY_DEVICE (1)  on the device, one file per lane: the host only copies the entropy bytes (stuffing undone) and the
  *                                compressed bytes cross PCIe; the walk of one file is serial (milliseconds), so this pays from
  *                                thousands of files per call;
- *   RPH_JPEG_ENTROPY_AUTO (2)    default: device from 2048 sequential files per call, host below.
+ *   RPH_JPEG_ENTROPY_AUTO (2)    default: device from 2048 lanes per call (a sequential file is one lane, or one per restart
+ *                                interval when it has restart markers), host below.
  * Progressive files are always decoded by the host threads.  Same results either way. */
 #define RPH_JPEG_ENTROPY_HOST 0
 #define RPH_JPEG_ENTROPY_DEVICE 1

@@ -689,7 +689,7 @@ constexpr size_t SUB_COEF_BYTES = (size_t)4 << 30;        // device entropy: rec
 constexpr size_t MAX_IMAGE_COEF_BYTES = (size_t)3 << 30;  // one image beyond this is refused (RPH_ERR_UNSUPPORTED)
 constexpr uint32_t CHUNK_MAX_IMAGES = 4096;               // host entropy
 constexpr size_t SUB_MAX_IMAGES = 16384;                  // images per reconstruction sub-batch (grid.y of the kernels: 3 planes each)
-constexpr uint32_t DEVICE_ENTROPY_MIN_FILES = 2048;       // automatic mode: below this the host decodes (latency)
+constexpr uint32_t DEVICE_ENTROPY_MIN_FILES = 2048;       // automatic mode: below this many lanes (files, or restart intervals) the host decodes (latency)
 
 // Huffman tables of a chunk, one per distinct content (most files of a collection share the four Annex K tables)
 struct TableStore {
@@ -1349,7 +1349,14 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
         else
             host_idx.push_back(i);
     }
-    if (ctx->jpeg_entropy == 2 && dev_idx.size() < DEVICE_ENTROPY_MIN_FILES) {
+    // automatic mode: the device walk pays when it has lanes to fill -- one per file, or one per restart interval where the frame
+    // header announces them (a few dozen photos with restart markers are thousands of short streams)
+    uint64_t lanes = 0;
+    for (uint32_t i : dev_idx) {
+        const rphj::Frame &f = jobs[i].frame;
+        lanes += f.restart_interval ? ((uint64_t)f.mcus_x * f.mcus_y + f.restart_interval - 1) / f.restart_interval : 1;
+    }
+    if (ctx->jpeg_entropy == 2 && lanes < DEVICE_ENTROPY_MIN_FILES) {
         host_idx.clear();
         for (uint32_t i = 0; i < n; i++) host_idx.push_back(i);
         dev_idx.clear();

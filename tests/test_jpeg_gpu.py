@@ -219,6 +219,24 @@ def test_one_file_per_call_from_many_threads(eng, oracle):
             assert np.array_equal(c.view(np.uint32), ref["coeffs"][i].view(np.uint32)), i
 
 
+def test_restart_intervals_get_a_lane_each(eng, oracle):
+    """one-scan files with restart markers are walked by one lane per interval; 60 photos with an interval per MCU row are 3 000+
+    lanes, so the automatic mode takes the device walk for them; hashes equal the host decoder's and the oracle's"""
+    base = [ju.pillow_jpeg(ju.make_image(640 + 16 * k, 400 + 8 * k, seed=70 + k), quality=88, subsampling=2 if k % 2 else 0, restart_marker_rows=1) for k in range(6)]
+    base += [ju.pillow_jpeg(ju.make_image(300, 200, "L", seed=80), quality=80, restart_marker_blocks=5)]
+    base += [ju.encode_baseline(np.array(ju.make_image(120, 90, seed=81)), ((2, 2), (1, 1), (1, 1)), 1.0, 3)]  # interval = 3 MCUs, the last one short
+    files = [base[k % len(base)] for k in range(64)]
+    eng.jpeg_set_entropy(0)
+    host = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    eng.jpeg_set_entropy(2)
+    auto = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    assert auto["valid"].all() and np.array_equal(auto["hash"], host["hash"])
+    assert np.array_equal(auto["coeffs"].view(np.uint32), host["coeffs"].view(np.uint32))
+    for k in range(len(base)):
+        ok, h, _, _ = _oracle_hash(oracle, oracle.jpeg_decode(base[k], 0))
+        assert ok and np.array_equal(auto["hash"][k], h)
+
+
 def test_default_threads_and_release(eng, oracle):
     """n_threads = 0 (affinity mask / cgroup quota decide), and the cached buffers can be returned and come back on the next call"""
     files = [ju.pillow_jpeg(ju.make_image(96 + k, 64, seed=k), quality=80) for k in range(40)]
