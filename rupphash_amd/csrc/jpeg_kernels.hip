@@ -823,7 +823,6 @@ struct ChunkDesc {
     size_t m = 0;
     size_t off_planes = 0, off_images = 0, off_tables = 0, off_end = 0;
     std::vector<uint32_t> image_of, plane_of;  // per chunk position: index of its JImage / first JPlane (UINT32_MAX: not decodable)
-    std::vector<uint32_t> n_blocks;            // per chunk position
     uint32_t n_planes = 0, n_images = 0;
 };
 
@@ -842,7 +841,6 @@ int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first
     uint16_t *hq = reinterpret_cast<uint16_t *>(h_meta + D.off_tables);
     D.image_of.assign(m, UINT32_MAX);
     D.plane_of.assign(m, UINT32_MAX);
-    D.n_blocks.assign(m, 0);
     D.n_planes = D.n_images = 0;
     sub_starts.clear();
     sub_starts.push_back(0);
@@ -860,7 +858,6 @@ int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first
         }
         sub_blocks += f.total_blocks;
         sub_images++;
-        D.n_blocks[r] = (uint32_t)f.total_blocks;
         JImage im;
         memset(&im, 0, sizeof im);
         D.plane_of[r] = D.n_planes;
