@@ -1,55 +1,26 @@
-// jpeg_kernels.hip -- device half of the JPEG path (row N3 of SURVEY 8f) and its C ABI.
+// jpeg_kernels.hip -- the device kernels of the JPEG path (row N3 of SURVEY 8f); the pipeline around them is jpeg_pipeline.cpp.
 //
 // The reference decodes "jpg" | "jpeg" files with zune-jpeg 0.5.15 into Luma8 / Rgb8 and hands the pixels to generate_pdq_features
-// (/root/reference/src/scanner.rs:473-508, :1410).  Here the host only undoes the entropy coding (jpeg_host.cpp: a serial bit
-// stream per image, one image per host thread); the quantised coefficients cross PCIe once and everything with arithmetic in it
-// runs on the device, a whole batch of images per launch:
+// (/root/reference/src/scanner.rs:473-508, :1410).  Here everything with arithmetic in it runs on the device, a batch of files per launch:
+//   jpeg_huff_kernel   the Huffman walk of sequential files, one file -- or one restart interval -- per lane (the host decodes progressive
+//                      files and small batches instead, jpeg_host.cpp): quantised coefficients written de-zigzagged into a dense buffer
 //   jpeg_idct_kernel   one lane per 8x8 block: dequantise, integer IDCT (columns, rows) entirely in registers, level shift, clamp;
 //                      128 B read and 64 B written per block -- HBM-bound, no LDS
-//   jpeg_color_kernel  one lane per 4 output pixels: chroma upsampling as a pure function of the position (no intermediate
-//                      full-resolution chroma planes), YCbCr -> RGB, packed Rgb8 (or Luma8 for one component) that the PDQ kernels read
-// and then the existing PDQ launchers hash the pixels where they lie.  Nothing returns to the host but the hashes.
+//   jpeg_color_kernel  one lane per 8 output pixels: chroma upsampling as a pure function of the position (no intermediate
+//                      full-resolution chroma planes), YCbCr -> RGB, then packed Rgb8, or the Rec.601 luma of it when only the hasher
+//                      reads the pixels (Luma8 for one component)
+// and then the PDQ launchers hash the pixels where they lie.
 //
 // Two arithmetic flavours (the tests' CPU checker restates the same pair):
 //   RPH_JPEG_ZUNE (default)  zune-jpeg as recalled: stb_image's integer IDCT, (3 a + b + 2) >> 2 upsampling per direction, 45/32-style
 //                            colour constants.  PARITY UNPINNED: the crate's source is not in the reference tree.
 //   RPH_JPEG_LIBJPEG         libjpeg-turbo's defaults (jidctint.c islow, jdsample.c fancy upsampling, jdcolor.c): pinned by the tests
 //                            against Pillow's decode of the reference's own JPEG files and of generated ones.
-#include <algorithm>
-#include <atomic>
-#include <cstring>
-#include <sched.h>
 
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <thread>
-#include <type_traits>
-#include <unordered_map>
-#include <vector>
-
-#include "jpeg_host.h"
+#include "jpeg_device.h"
 #include "rph_internal.h"
 
 namespace {
-
-struct JPlane {            // one per component of each decoded image
-    uint64_t first_block;  // in the chunk's coefficient buffer
-    uint64_t out_off;      // byte offset of the sample plane in the chunk's plane buffer
-    uint32_t blocks_w, blocks_h;
-    uint32_t qt;           // index of the plane's 64-entry table in the chunk's table buffer
-    uint32_t pitch;        // blocks_w * 8
-};
-struct JImage {
-    uint64_t plane_off[3];  // sample planes (Y, Cb, Cr)
-    uint64_t out_off;       // packed pixels
-    uint32_t w, h, ncomp;
-    uint32_t hs, vs;        // chroma upsampling factors (1 or 2)
-    uint32_t pitch[3];
-    uint32_t cw, ch;        // chroma samples the upsampler may use: real component samples (libjpeg) or the padded plane (zune)
-    uint32_t out_stride;    // bytes per output row: channels * align8(w)
-    uint32_t luma_out;      // three components, but the hasher is the only reader: write Rec.601 luma (what to_luma601 makes of the RGB) instead of Rgb8
-};
 
 #define MUL(a, b) ((int32_t)((uint32_t)(a) * (uint32_t)(b)))
 #define ADD(a, b) ((int32_t)((uint32_t)(a) + (uint32_t)(b)))
@@ -349,32 +320,6 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const uint8_t *__restri
 // and stays with the host decoder.  Latency per image is milliseconds (the walk is serial), so this is the path for large batches
 // only (rph_jpeg_set_entropy).
 // ---------------------------------------------------------------------------------------------------------------------------
-struct HComp {
-    uint32_t blocks_w, real_bw, real_bh, first_block;
-    uint32_t H, V;
-};
-struct HScan {
-    uint32_t off, len, restart_interval, ns;
-    uint32_t ci[3];
-    uint32_t dc[3], ac[3];  // indices into the chunk's table array
-};
-struct HImage {
-    uint64_t first_block;  // of the image in the chunk's coefficient buffer
-    uint64_t stream_base;  // of the image's de-stuffed entropy bytes in the chunk's stream buffer
-    uint32_t mcus_x, mcus_y, n_scans, ncomp;
-    HComp comp[3];
-    HScan scan[4];
-};
-
-// One lane's work: a whole image (scan == HITEM_ALL_SCANS: its scans one after the other, restart intervals handled in the walk), or ONE
-// restart interval of a single-scan image: mcu_count MCUs from mcu_first, whose bits begin stream_off bytes into the scan -- every
-// restart interval is an independent stream (predictions reset, byte aligned), so a file with restart markers is walked by as many
-// lanes as it has intervals.
-constexpr uint32_t HITEM_ALL_SCANS = 0xFFFFFFFFu;
-struct HItem {
-    uint32_t image, scan, mcu_first, mcu_count, stream_off;
-};
-
 __constant__ uint8_t c_zigzag[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
                                      6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
                                      39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
@@ -392,7 +337,6 @@ __device__ __forceinline__ T sel3(uint32_t i, T a, T b, T c)
 // LDS_TABLES > 0: the chunk has at most that many distinct Huffman tables (a photo collection usually has the four Annex K tables) and
 // every wave keeps a copy in LDS: the table lookup is on the critical path of every symbol, and an LDS read returns in a tenth of the
 // time of a cached global read.
-constexpr int HUFF_LDS_TABLES = 8;
 template <int LDS_TABLES>
 __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const HItem *__restrict__ items,
                                                        const uint32_t *__restrict__ order, uint32_t n, const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts,
@@ -558,1089 +502,40 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
     if (bad) status[ii] = 1;  // (the results were zeroed before the launch; several lanes may share an image)
 }
 
-#define RPH_TRY(expr)                  \
-    do {                               \
-        int rc_ = (expr);              \
-        if (rc_ != RPH_OK) return rc_; \
-    } while (0)
 
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}  // namespace
 
-// A pinned host buffer with its device twin, grown on demand (the caller has synchronised the stream that used it)
-struct Twin {
-    uint8_t *h = nullptr, *d = nullptr;
-    size_t cap = 0;
-    void release()
-    {
-        if (h) (void)hipHostFree(h);
-        if (d) (void)hipFree(d);
-        h = d = nullptr;
-        cap = 0;
-    }
-    int reserve(size_t bytes, bool host = true, bool dev = true)
-    {
-        if (cap >= bytes) return RPH_OK;
-        release();
-        bytes = align_up(bytes + bytes / 4, 4096);
-        if (host) RPH_HIP_CHECK(hipHostMalloc((void **)&h, bytes));
-        if (dev) RPH_HIP_CHECK(hipMalloc((void **)&d, bytes));
-        cap = bytes;
-        return RPH_OK;
-    }
-};
-
-constexpr size_t RES_BYTES = 32 + 4 + 1024 + 256 + 4;  // per image: hash, quality, coefficients, dihedral, valid + entropy status (padded)
-struct ResView {  // the per-image result arrays inside one buffer laid out for `images` images
-    uint8_t *hash, *quality, *coeffs, *dihedral, *valid, *status;
-    ResView(uint8_t *p, size_t images)
-    {
-        hash = p;
-        quality = hash + images * 32;
-        coeffs = quality + images * 4;
-        dihedral = coeffs + images * 1024;
-        valid = dihedral + images * 256;
-        status = valid + images;
-    }
-};
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// The pipeline.  One JPEG batch call per context at a time (ctx->jpeg_mu); buffers are kept in the context across calls.
-//   host entropy:   chunks of <= 192 MB of coefficients, two slots: the host threads decode chunk k + 1 while the device works on k
-//   device entropy: chunks as large as the coefficient buffer allows (tens of thousands of images: one per lane), the host only
-//                   prepares streams; reconstruction + hashing then runs over the chunk in sub-batches through small buffers
-// ---------------------------------------------------------------------------------------------------------------------------
-struct Slot {
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;  // device entropy: the slot's chunk (work on another slot's stream) has delivered its results
-    Twin coef;              // host entropy: pinned staging + device; device entropy: unused
-    Twin stream_bytes;      // device entropy: de-stuffed entropy bytes
-    Twin meta;              // descriptors (planes | images | tables | HImage | order | DeviceLut)
-    Twin res;               // results
-    size_t res_images = 0;
-    void release()
-    {
-        if (stream) (void)hipStreamSynchronize(stream);
-        coef.release();
-        stream_bytes.release();
-        meta.release();
-        res.release();
-        if (stream) (void)hipStreamDestroy(stream);
-        if (done) (void)hipEventDestroy(done);
-        *this = Slot();
-    }
-    int ready()
-    {
-        if (!stream) RPH_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        if (!done) RPH_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        return RPH_OK;
-    }
-    int reserve_res(size_t images)  // the caller has made sure nothing in flight still uses the slot's buffers
-    {
-        if (res_images >= images) return RPH_OK;
-        RPH_HIP_CHECK(hipStreamSynchronize(stream));
-        images += images / 4;
-        RPH_TRY(res.reserve(images * RES_BYTES));
-        res_images = images;
-        return RPH_OK;
-    }
-};
-struct JpegPipe {
-    Slot slot[2];
-    // reconstruction buffers (sample planes, packed pixels) shared by the slots' sub-batches: used in stream order, one sub-batch at a
-    // time per stream; each slot owns one pair
-    uint8_t *d_planes[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
-    size_t recon_coef_bytes[2] = {0, 0};
-    // device entropy: the chunk's coefficient buffer (one: chunks run back to back on one stream)
-    int16_t *d_coef = nullptr;
-    size_t d_coef_bytes = 0;
-    void release()
-    {
-        slot[0].release();
-        slot[1].release();
-        for (int b = 0; b < 2; b++) {
-            if (d_planes[b]) (void)hipFree(d_planes[b]);
-            if (d_out[b]) (void)hipFree(d_out[b]);
-            d_planes[b] = d_out[b] = nullptr;
-            recon_coef_bytes[b] = 0;
-        }
-        if (d_coef) (void)hipFree(d_coef);
-        d_coef = nullptr;
-        d_coef_bytes = 0;
-    }
-    // sample planes and packed pixels for sub-batches of up to `coef_need` bytes of coefficients
-    int reserve_recon(int b, size_t coef_need, hipStream_t s)
-    {
-        if (recon_coef_bytes[b] >= coef_need) return RPH_OK;
-        RPH_HIP_CHECK(hipStreamSynchronize(s));
-        if (d_planes[b]) (void)hipFree(d_planes[b]);
-        if (d_out[b]) (void)hipFree(d_out[b]);
-        d_planes[b] = d_out[b] = nullptr;
-        recon_coef_bytes[b] = 0;
-        RPH_HIP_CHECK(hipMalloc((void **)&d_planes[b], coef_need / 2 + 256));  // 64 bytes of samples per 128 bytes of coefficients
-        // packed pixels never exceed the coefficient bytes (4:2:0: both 3 w h; Luma8: w h against 2 w h), plus row / image padding
-        RPH_HIP_CHECK(hipMalloc((void **)&d_out[b], coef_need + coef_need / 8 + 65536));
-        recon_coef_bytes[b] = coef_need;
-        return RPH_OK;
-    }
-};
-
-constexpr size_t CHUNK_COEF_BYTES = (size_t)192 << 20;   // host entropy, per slot: ~250 images of 512x512 4:2:0
-constexpr size_t SUB_COEF_BYTES = (size_t)4 << 30;        // device entropy: reconstruction sub-batch (~5400 such images)
-constexpr size_t MAX_IMAGE_COEF_BYTES = (size_t)3 << 30;  // one image beyond this is refused (RPH_ERR_UNSUPPORTED)
-constexpr uint32_t CHUNK_MAX_IMAGES = 4096;               // host entropy
-constexpr size_t SUB_MAX_IMAGES = 16384;                  // images per reconstruction sub-batch (grid.y of the kernels: 3 planes each)
-constexpr uint32_t DEVICE_ENTROPY_MIN_FILES = 2048;       // automatic mode: below this many lanes (files, or restart intervals) the host decodes (latency)
-
-// Huffman tables of a chunk, one per distinct content (most files of a collection share the four Annex K tables)
-struct TableStore {
-    std::mutex mu;
-    std::vector<rphj::DeviceLut> luts;
-    std::vector<rphj::TableSpec> specs;
-    std::unordered_multimap<uint64_t, uint32_t> by_hash;
-    static uint32_t intern(void *self, const rphj::TableSpec &t)
-    {
-        TableStore &T = *static_cast<TableStore *>(self);
-        uint64_t h = 1469598103934665603ULL;
-        for (int q = 1; q <= 16; q++) h = (h ^ t.counts[q]) * 1099511628211ULL;
-        for (int q = 0; q < t.total; q++) h = (h ^ t.symbols[q]) * 1099511628211ULL;
-        std::lock_guard<std::mutex> lock(T.mu);
-        auto range = T.by_hash.equal_range(h);
-        for (auto it = range.first; it != range.second; ++it) {
-            const rphj::TableSpec &o = T.specs[it->second];
-            if (o.total == t.total && memcmp(o.counts + 1, t.counts + 1, 16) == 0 && memcmp(o.symbols, t.symbols, t.total) == 0) return it->second;
-        }
-        rphj::DeviceLut L;
-        if (rphj::build_device_lut(t, L) != RPH_OK) return UINT32_MAX;
-        T.luts.push_back(L);
-        T.specs.push_back(t);
-        T.by_hash.emplace(h, (uint32_t)T.luts.size() - 1);
-        return (uint32_t)T.luts.size() - 1;
-    }
-};
-
-struct Job {
-    Job() {}  // user-provided on purpose: std::vector<Job>(n) then runs the member initialisers only instead of zeroing ~1 KB per job first
-    const uint8_t *data = nullptr;
-    size_t len = 0;
-    rphj::Frame frame;
-    int status = RPH_OK;
-    uint64_t first_block = 0;  // within the chunk's coefficient buffer
-    rphj::StreamPlan plan;     // device entropy
-    const int16_t *pre = nullptr;  // coefficients already decoded by the caller into pinned memory (rph_jpeg_pdq_hash_one)
-    std::vector<uint32_t> marks;   // device entropy: where the restart intervals of a one-scan file begin (empty: walk the file with one lane)
-    size_t stream_off = 0, stream_used = 0;
-};
-
-using Jobs = std::vector<Job>;
-
-// Channels of the pixels the device writes for a file: Rgb8 only where the caller reads RGB (rph_jpeg_decode); a colour file that
-// only the hasher reads is written as its Rec.601 luma (a third of the bytes, and the PDQ paths start from luma anyway: Luma8 input
-// is borrowed as it is, pdqhash.rs:176; 512x512 Luma8 has its own form of the fused kernel)
-inline uint32_t out_channels(const rphj::Frame &f, bool rgb_wanted) { return (f.ncomp == 1 || !rgb_wanted) ? 1u : 3u; }
-
-size_t out_bytes_of(const rphj::Frame &f, uint32_t channels)
+int rph_jpeg_launch_idct(int flavour, uint32_t max_blocks, uint32_t n_planes, hipStream_t stream, const int16_t *d_coef, const uint16_t *d_tables, const JPlane *d_planes,
+                         uint8_t *d_samples)
 {
-    const size_t stride = (size_t)channels * align_up(f.w, 8);
-    return align_up(stride * f.h, 64);
-}
-
-inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-inline int trace_level()  // RPH_JPEG_TRACE=1: synchronise after every device phase and print its time; 2: host-side timestamps only (no extra synchronisation)
-{
-    static const int level = getenv("RPH_JPEG_TRACE") ? atoi(getenv("RPH_JPEG_TRACE")) : 0;
-    return level;
-}
-inline bool trace_on() { return trace_level() == 1; }
-#define RPH_JPEG_STAMP(...)                                   \
-    do {                                                      \
-        if (trace_level() == 2) {                             \
-            fprintf(stderr, "[rph_jpeg %9.1f ms] ", now_ms() - g_trace_t0); \
-            fprintf(stderr, __VA_ARGS__);                     \
-            fprintf(stderr, "\n");                            \
-        }                                                     \
-    } while (0)
-static double g_trace_t0 = 0;
-
-// Host threads when the caller does not say: what this process may actually use (its affinity mask, and the cgroup CPU quota a
-// container runs under -- hardware_concurrency() reports the machine's 256 threads inside a 16-CPU container)
-unsigned default_threads()
-{
-    unsigned n = std::max(1u, std::thread::hardware_concurrency());
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
-    long long quota = -1, period = 100000;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "max 100000" or "1600000 100000"
-        char q[32] = "";
-        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-        fclose(f);
-    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
-        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
-        fclose(g);
-        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-            if (fscanf(h, "%lld", &period) != 1) period = 100000;
-            fclose(h);
-        }
-    }
-    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
-    return n;
-}
-
-template <class F>
-void parallel_for(size_t first, size_t last, unsigned threads, F &&body)
-{
-    std::atomic<size_t> next{first};
-    auto work = [&]() {
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= last) return;
-            body(i);
-        }
-    };
-    const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, threads), last > first ? last - first : 1);
-    if (nt <= 1) {
-        work();
-        return;
-    }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t + 1 < nt; t++) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
-}
-
-struct Outputs {
-    uint8_t *hash = nullptr;
-    float *quality = nullptr;
-    float *coeffs = nullptr;
-    uint8_t *dihedral = nullptr;
-    uint8_t *valid = nullptr;
-    int32_t *status = nullptr;
-    uint8_t *pixels = nullptr;  // single-image decode: packed w * h * channels
-    bool want_hash = true;
-};
-
-// Descriptors of the chunk idx[first..last) and where they live in the slot's meta buffer (host and device at the same offsets)
-struct ChunkDesc {
-    size_t m = 0;
-    size_t off_planes = 0, off_images = 0, off_tables = 0, off_end = 0;
-    std::vector<uint32_t> image_of, plane_of;  // per chunk position: index of its JImage / first JPlane (UINT32_MAX: not decodable)
-    uint32_t n_planes = 0, n_images = 0;
-};
-
-// Sub-batch boundaries are where the offsets of planes and pixels restart from 0: `sub_of[r]` = first chunk position of r's sub-batch.
-int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, int flavour, bool rgb_wanted, size_t sub_coef_bytes, uint8_t *h_meta,
-                      size_t meta_base, ChunkDesc &D, std::vector<size_t> &sub_starts)
-{
-    const size_t m = last - first;
-    D.m = m;
-    D.off_planes = meta_base;
-    D.off_images = D.off_planes + m * 3 * sizeof(JPlane);
-    D.off_tables = D.off_images + m * sizeof(JImage);
-    D.off_end = D.off_tables + m * 3 * 128;
-    JPlane *hp = reinterpret_cast<JPlane *>(h_meta + D.off_planes);
-    JImage *hi = reinterpret_cast<JImage *>(h_meta + D.off_images);
-    uint16_t *hq = reinterpret_cast<uint16_t *>(h_meta + D.off_tables);
-    D.image_of.assign(m, UINT32_MAX);
-    D.plane_of.assign(m, UINT32_MAX);
-    D.n_planes = D.n_images = 0;
-    sub_starts.clear();
-    sub_starts.push_back(0);
-    size_t plane_bytes = 0, out_bytes = 0, sub_blocks = 0, sub_images = 0;
-    for (size_t r = 0; r < m; r++) {
-        Job &j = jobs[idx[first + r]];
-        if (j.status != RPH_OK) continue;
-        const rphj::Frame &f = j.frame;
-        // a sub-batch is full when its coefficients would not fit the reconstruction buffers, or at 16 384 images (the kernels take
-        // the plane / image index from blockIdx.y, which ends at 65 535): offsets restart
-        if (sub_blocks && ((sub_blocks + f.total_blocks) * 128 > sub_coef_bytes || sub_images == SUB_MAX_IMAGES)) {
-            sub_starts.push_back(r);
-            plane_bytes = out_bytes = sub_blocks = 0;
-            sub_images = 0;
-        }
-        sub_blocks += f.total_blocks;
-        sub_images++;
-        JImage im;
-        memset(&im, 0, sizeof im);
-        D.plane_of[r] = D.n_planes;
-        for (int c = 0; c < f.ncomp; c++) {
-            const rphj::Comp &kc = f.comp[c];
-            JPlane pl;
-            pl.first_block = j.first_block + kc.first_block;
-            pl.out_off = plane_bytes;
-            pl.blocks_w = kc.blocks_w;
-            pl.blocks_h = kc.blocks_h;
-            pl.qt = D.n_planes;
-            pl.pitch = kc.blocks_w * 8;
-            memcpy(hq + (size_t)D.n_planes * 64, f.qt[kc.tq], 128);
-            im.plane_off[c] = plane_bytes;
-            im.pitch[c] = pl.pitch;
-            plane_bytes += (size_t)pl.pitch * kc.blocks_h * 8;
-            hp[D.n_planes++] = pl;
-        }
-        im.w = f.w;
-        im.h = f.h;
-        im.ncomp = (uint32_t)f.ncomp;
-        im.hs = im.vs = 1;
-        if (f.ncomp == 3) {
-            im.hs = f.comp[0].H / f.comp[1].H;
-            im.vs = f.comp[0].V / f.comp[1].V;
-            im.cw = flavour == RPH_JPEG_LIBJPEG ? f.comp[1].samp_w : f.comp[1].blocks_w * 8;
-            im.ch = flavour == RPH_JPEG_LIBJPEG ? f.comp[1].samp_h : f.comp[1].blocks_h * 8;
-        }
-        const uint32_t och = out_channels(f, rgb_wanted);
-        im.luma_out = f.ncomp == 3 && och == 1;
-        im.out_stride = (uint32_t)((size_t)och * align_up(f.w, 8));
-        im.out_off = out_bytes;
-        out_bytes += out_bytes_of(f, och);
-        D.image_of[r] = D.n_images;
-        hi[D.n_images++] = im;
-    }
-    return RPH_OK;
-}
-
-// IDCT + upsampling / colour + hashing of chunk positions [r0, r1) (one sub-batch: its planes and pixels fit the slot's reconstruction buffers)
-int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, Jobs &jobs, const std::vector<uint32_t> &idx, size_t first, const ChunkDesc &D, size_t r0,
-                         size_t r1, const int16_t *d_coef, int flavour, const Outputs &out, hipStream_t s)
-{
-    // the planes and images of the sub-batch are contiguous in the descriptor arrays
-    uint32_t p0 = UINT32_MAX, p1 = 0, i0 = UINT32_MAX, i1 = 0, max_blocks = 0, max_groups = 0;
-    for (size_t r = r0; r < r1; r++) {
-        if (D.image_of[r] == UINT32_MAX) continue;
-        const rphj::Frame &f = jobs[idx[first + r]].frame;
-        p0 = std::min(p0, D.plane_of[r]);
-        p1 = std::max(p1, D.plane_of[r] + (uint32_t)f.ncomp);
-        i0 = std::min(i0, D.image_of[r]);
-        i1 = std::max(i1, D.image_of[r] + 1);
-        for (int c = 0; c < f.ncomp; c++) max_blocks = std::max(max_blocks, f.comp[c].blocks_w * f.comp[c].blocks_h);
-        max_groups = std::max<uint32_t>(max_groups, (uint32_t)(((f.w + 7) / 8) * (size_t)f.h));
-    }
-    if (i0 == UINT32_MAX) return RPH_OK;
-    const JPlane *dp = reinterpret_cast<const JPlane *>(S.meta.d + D.off_planes) + p0;
-    const JImage *di = reinterpret_cast<const JImage *>(S.meta.d + D.off_images) + i0;
-    const uint16_t *dq = reinterpret_cast<const uint16_t *>(S.meta.d + D.off_tables);
-    const dim3 gi((max_blocks + 255) / 256, p1 - p0), gc((max_groups + 255) / 256, i1 - i0);
-    if (flavour == RPH_JPEG_LIBJPEG) {
-        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_LIBJPEG>, gi, dim3(256), 0, s, d_coef, dq, dp, P.d_planes[b]);
-        hipLaunchKernelGGL(jpeg_color_kernel<RPH_JPEG_LIBJPEG>, gc, dim3(256), 0, s, P.d_planes[b], di, P.d_out[b]);
-    } else {
-        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_ZUNE>, gi, dim3(256), 0, s, d_coef, dq, dp, P.d_planes[b]);
-        hipLaunchKernelGGL(jpeg_color_kernel<RPH_JPEG_ZUNE>, gc, dim3(256), 0, s, P.d_planes[b], di, P.d_out[b]);
-    }
+    const dim3 grid((max_blocks + 255) / 256, n_planes);
+    if (flavour == RPH_JPEG_LIBJPEG)
+        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_LIBJPEG>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_samples);
+    else
+        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_ZUNE>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_samples);
     RPH_HIP_CHECK(hipGetLastError());
-    if (!out.want_hash) return RPH_OK;
-    // hash runs of equal geometry where the pixels lie (generate_pdq_features, scanner.rs:1410)
-    ResView R(S.res.d, S.res_images);
-    const JImage *hi = reinterpret_cast<const JImage *>(S.meta.h + D.off_images);
-    for (size_t r = r0; r < r1;) {
-        if (D.image_of[r] == UINT32_MAX) {
-            r++;
-            continue;
-        }
-        const rphj::Frame &f = jobs[idx[first + r]].frame;
-        const uint32_t och = out_channels(f, out.pixels != nullptr);
-        size_t e = r + 1;
-        while (e < r1 && D.image_of[e] != UINT32_MAX && jobs[idx[first + e]].frame.w == f.w && jobs[idx[first + e]].frame.h == f.h && jobs[idx[first + e]].frame.ncomp == f.ncomp) e++;
-        RPH_TRY(rph_pdq_hash_batch_dev(ctx, P.d_out[b] + hi[D.image_of[r]].out_off, (uint32_t)(e - r), f.w, f.h, och, (size_t)och * align_up(f.w, 8), out_bytes_of(f, och),
-                                       R.hash + r * 32, out.quality ? R.quality + r * 4 : nullptr, out.coeffs ? R.coeffs + r * 1024 : nullptr,
-                                       out.dihedral ? R.dihedral + r * 256 : nullptr, R.valid + r, s));
-        r = e;
-    }
     return RPH_OK;
 }
 
-// The results of a chunk are fetched only when the chunk is known to be finished.  Enqueued behind the chunk's kernels instead, the
-// transfer would sit in the copy engine's queue waiting for them, and the next chunk's upload -- same engine, another stream --
-// would wait behind it (measured: uploads did not overlap the other lane's kernels at all).
-int fetch_results(Slot &S, size_t m, const Outputs &out, bool entropy_status)
+int rph_jpeg_launch_color(int flavour, uint32_t max_groups, uint32_t n_images, hipStream_t stream, const uint8_t *d_samples, const JImage *d_images, uint8_t *d_pixels)
 {
-    ResView H(S.res.h, S.res_images), D(S.res.d, S.res_images);
-    if (out.want_hash) {
-        RPH_HIP_CHECK(hipMemcpy(H.hash, D.hash, m * 32, hipMemcpyDeviceToHost));
-        if (out.quality) RPH_HIP_CHECK(hipMemcpy(H.quality, D.quality, m * 4, hipMemcpyDeviceToHost));
-        if (out.coeffs) RPH_HIP_CHECK(hipMemcpy(H.coeffs, D.coeffs, m * 1024, hipMemcpyDeviceToHost));
-        if (out.dihedral) RPH_HIP_CHECK(hipMemcpy(H.dihedral, D.dihedral, m * 256, hipMemcpyDeviceToHost));
-        RPH_HIP_CHECK(hipMemcpy(H.valid, D.valid, m, hipMemcpyDeviceToHost));
-    }
-    if (entropy_status) RPH_HIP_CHECK(hipMemcpy(H.status, D.status, m, hipMemcpyDeviceToHost));
+    const dim3 grid((max_groups + 255) / 256, n_images);
+    if (flavour == RPH_JPEG_LIBJPEG)
+        hipLaunchKernelGGL(jpeg_color_kernel<RPH_JPEG_LIBJPEG>, grid, dim3(256), 0, stream, d_samples, d_images, d_pixels);
+    else
+        hipLaunchKernelGGL(jpeg_color_kernel<RPH_JPEG_ZUNE>, grid, dim3(256), 0, stream, d_samples, d_images, d_pixels);
+    RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }
 
-// results of a finished chunk -> the caller's arrays (scattered through idx)
-void scatter_results(const Slot &S, Jobs &jobs, const std::vector<uint32_t> &idx, size_t first, size_t last, const Outputs &out, bool entropy_status)
+int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const HItem *d_items, const uint32_t *d_order, uint32_t n_items,
+                         const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status)
 {
-    ResView R(S.res.h, S.res_images);
-    for (size_t r = 0; r < last - first; r++) {
-        const uint32_t g = idx[first + r];
-        Job &j = jobs[g];
-        if (entropy_status && j.status == RPH_OK && R.status[r]) j.status = RPH_ERR_INVALID_ARG;  // the device walk met a corrupt stream
-        const bool ok = j.status == RPH_OK;
-        if (out.hash) ok ? (void)memcpy(out.hash + (size_t)g * 32, R.hash + r * 32, 32) : (void)memset(out.hash + (size_t)g * 32, 0, 32);
-        if (out.quality) ok ? (void)memcpy(out.quality + g, R.quality + r * 4, 4) : (void)memset(out.quality + g, 0, 4);
-        if (out.coeffs) ok ? (void)memcpy(out.coeffs + (size_t)g * 256, R.coeffs + r * 1024, 1024) : (void)memset(out.coeffs + (size_t)g * 256, 0, 1024);
-        if (out.dihedral) ok ? (void)memcpy(out.dihedral + (size_t)g * 256, R.dihedral + r * 256, 256) : (void)memset(out.dihedral + (size_t)g * 256, 0, 256);
-        if (out.valid) out.valid[g] = ok ? R.valid[r] : 0;
-    }
-}
-
-// ---- host entropy decoding: the files idx[...] in chunks over the two slots
-int run_host_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, const std::vector<uint32_t> &idx, int flavour, unsigned threads, const Outputs &out)
-{
-    struct Pending {
-        bool active = false;
-        size_t first = 0, last = 0;
-    } pend[2];
-    auto finish = [&](int b) -> int {
-        if (!pend[b].active) return RPH_OK;
-        RPH_HIP_CHECK(hipStreamSynchronize(P.slot[b].stream));
-        RPH_TRY(fetch_results(P.slot[b], pend[b].last - pend[b].first, out, false));
-        scatter_results(P.slot[b], jobs, idx, pend[b].first, pend[b].last, out, false);
-        pend[b].active = false;
-        return RPH_OK;
-    };
-    const size_t n = idx.size();
-    int k = 0;
-    for (size_t first = 0; first < n; k++) {
-        size_t last = first, blocks = 0;
-        while (last < n && last - first < CHUNK_MAX_IMAGES) {
-            const Job &j = jobs[idx[last]];
-            const size_t nb = j.status == RPH_OK ? (size_t)j.frame.total_blocks : 0;
-            if (last > first && (blocks + nb) * 128 > CHUNK_COEF_BYTES) break;
-            blocks += nb;
-            last++;
-        }
-        const int b = k & 1;
-        RPH_TRY(finish(b));
-        Slot &S = P.slot[b];
-        RPH_TRY(S.ready());
-        const size_t m = last - first;
-        const size_t coef_need = std::max(CHUNK_COEF_BYTES, blocks * 128);
-        if (S.coef.cap < coef_need) {
-            RPH_HIP_CHECK(hipStreamSynchronize(S.stream));
-            RPH_TRY(S.coef.reserve(coef_need));
-        }
-        RPH_TRY(P.reserve_recon(b, coef_need, S.stream));
-        RPH_TRY(S.reserve_res(std::max<size_t>(m, std::min<size_t>(n, CHUNK_MAX_IMAGES))));
-        const size_t meta_need = std::max<size_t>(m, std::min<size_t>(n, CHUNK_MAX_IMAGES)) * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128);
-        if (S.meta.cap < meta_need) {
-            RPH_HIP_CHECK(hipStreamSynchronize(S.stream));
-            RPH_TRY(S.meta.reserve(meta_need));
-        }
-        {
-            uint64_t fb = 0;
-            for (size_t i = first; i < last; i++) {
-                Job &j = jobs[idx[i]];
-                j.first_block = fb;
-                if (j.status == RPH_OK) fb += j.frame.total_blocks;
-            }
-        }
-        int16_t *h_coef = reinterpret_cast<int16_t *>(S.coef.h);
-        bool predecoded = false;
-        for (size_t i = first; i < last; i++) predecoded |= jobs[idx[i]].pre != nullptr;
-        if (!predecoded)
-            parallel_for(first, last, threads, [&](size_t i) {
-                Job &j = jobs[idx[i]];
-                if (j.status == RPH_OK) j.status = rphj::decode_coefficients(j.data, j.len, j.frame, h_coef + j.first_block * 64);
-            });
-        ChunkDesc D;
-        std::vector<size_t> subs;
-        RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, out.pixels != nullptr, SIZE_MAX / 256, S.meta.h, 0, D, subs));
-        hipStream_t s = S.stream;
-        RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
-        if (D.n_images) {
-            if (predecoded) {  // every caller decoded into its own pinned buffer: the copy engine takes the coefficients from there
-                for (size_t i = first; i < last; i++) {
-                    const Job &j = jobs[idx[i]];
-                    if (j.status == RPH_OK)
-                        RPH_HIP_CHECK(hipMemcpyAsync(S.coef.d + j.first_block * 128, j.pre, (size_t)j.frame.total_blocks * 128, hipMemcpyHostToDevice, s));
-                }
-            } else {
-                RPH_HIP_CHECK(hipMemcpyAsync(S.coef.d, S.coef.h, blocks * 128, hipMemcpyHostToDevice, s));
-            }
-            RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, D.off_end, hipMemcpyHostToDevice, s));
-            RPH_TRY(reconstruct_and_hash(ctx, P, b, S, jobs, idx, first, D, 0, m, reinterpret_cast<const int16_t *>(S.coef.d), flavour, out, s));
-        }
-        if (out.pixels && m == 1 && jobs[idx[first]].status == RPH_OK) {  // single-image decode: rows without their padding
-            const rphj::Frame &f = jobs[idx[first]].frame;
-            const size_t row = (size_t)f.ncomp * f.w, stride = (size_t)f.ncomp * align_up(f.w, 8);
-            RPH_HIP_CHECK(hipMemcpy2DAsync(out.pixels, row, P.d_out[b], stride, row, f.h, hipMemcpyDeviceToHost, s));
-        }
-        pend[b].active = true;
-        pend[b].first = first;
-        pend[b].last = last;
-        first = last;
-    }
-    RPH_TRY(finish(k & 1));
-    RPH_TRY(finish((k + 1) & 1));
+    const dim3 grid((n_items + 63) / 64);
+    if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
+        hipLaunchKernelGGL(jpeg_huff_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, stream, d_streams, d_images, d_items, d_order, n_items, d_luts, n_luts, d_coef, d_status);
+    else
+        hipLaunchKernelGGL(jpeg_huff_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_items, d_order, n_items, d_luts, n_luts, d_coef, d_status);
+    RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }
-
-// ---- device entropy decoding: the sequential files idx[...]; files the device walk does not take come back in `leftover` for the host
-int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32_t> idx, int flavour, unsigned threads, const Outputs &out,
-                       std::vector<uint32_t> &leftover)
-{
-    // images of similar stream length share a wave: sort the whole list by file length first (chunks then are slices of it)
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return jobs[a].len > jobs[b].len; });
-    // the chunk's coefficient buffer: as much of the free device memory as is reasonable, but no more than this call can use
-    size_t need = 0;
-    for (uint32_t g : idx) need += (size_t)jobs[g].frame.total_blocks * 128;
-    size_t free_b = 0, total_b = 0;
-    RPH_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    const size_t budget = std::max<size_t>((size_t)1 << 30, std::min<size_t>((free_b + P.d_coef_bytes) / 2, (size_t)96 << 30));
-    // Two lanes of resources (stream, staging, half of the coefficient buffer, reconstruction buffers), chunks alternate between
-    // them: the host prepares chunk k + 1 and its bytes cross PCIe while chunk k is on the device, and the latency-bound walk of one
-    // chunk runs beside the bandwidth-bound reconstruction of the other.  A call is cut into about four chunks when it is large
-    // enough for each to still fill the device's lanes (16 GB of coefficients = 20 000 images of 512x512); a smaller call is one chunk.
-    // The walk of a chunk takes as long as its longest file (~0.65 us per entropy byte: 21 ms for 29 KB files, 236 ms for 366 KB photos)
-    // however few files it has, and walks of different chunks only overlap pairwise (two lanes): small files are cut into four chunks
-    // for the pipelining, photo-sized files into two so that the walks are not paid four times.
-    size_t max_len = 0;  // longest stream one lane will walk: a file, or one restart interval of it (as the frame header announces them)
-    for (uint32_t g : idx) {
-        const rphj::Frame &f = jobs[g].frame;
-        const uint64_t mcus = (uint64_t)f.mcus_x * f.mcus_y, intervals = f.restart_interval ? (mcus + f.restart_interval - 1) / f.restart_interval : 1;
-        max_len = std::max(max_len, jobs[g].len / (size_t)std::max<uint64_t>(1, intervals));
-    }
-    size_t min_chunk = (size_t)16 << 30, parts = 0.65e-6 * (double)max_len > 0.08 ? 2 : 4;
-    if (const char *e = getenv("RPH_JPEG_CHUNK_GB")) min_chunk = (size_t)atoi(e) << 30;  // experiments
-    if (const char *e = getenv("RPH_JPEG_PARTS")) parts = (size_t)atoi(e);
-    const size_t chunk_target = std::min(need, std::max(need / parts + 128, min_chunk));
-    const bool single = need <= chunk_target && need <= budget;
-    const size_t want = single ? need : std::min(budget, 2 * chunk_target);
-    if (P.d_coef_bytes < want) {
-        RPH_HIP_CHECK(hipDeviceSynchronize());
-        if (P.d_coef) (void)hipFree(P.d_coef);
-        P.d_coef = nullptr;
-        P.d_coef_bytes = 0;
-        RPH_HIP_CHECK(hipMalloc((void **)&P.d_coef, want));
-        P.d_coef_bytes = want;
-    }
-    const size_t region = (single ? P.d_coef_bytes : P.d_coef_bytes / 2) / 128 * 128;
-    const size_t chunk_bytes = std::min(region, chunk_target);
-    struct Pending {
-        bool active = false;
-        size_t first = 0, last = 0;
-    } pend[2];
-    auto finish = [&](int b) -> int {
-        if (!pend[b].active) return RPH_OK;
-        RPH_JPEG_STAMP("lane %d: waiting for its chunk", b);
-        RPH_HIP_CHECK(hipEventSynchronize(P.slot[b].done));
-        RPH_JPEG_STAMP("lane %d: chunk done", b);
-        RPH_TRY(fetch_results(P.slot[b], pend[b].last - pend[b].first, out, true));
-        scatter_results(P.slot[b], jobs, idx, pend[b].first, pend[b].last, out, true);
-        RPH_JPEG_STAMP("lane %d: results scattered", b);
-        pend[b].active = false;
-        return RPH_OK;
-    };
-    RPH_TRY(P.slot[0].ready());
-    RPH_TRY(P.slot[1].ready());
-    {
-        size_t max_img = 0;  // a sub-batch holds at least one image
-        for (uint32_t g : idx) max_img = std::max(max_img, (size_t)jobs[g].frame.total_blocks * 128);
-        const size_t recon = std::max(std::min(SUB_COEF_BYTES, std::max(std::min(want, chunk_bytes), (size_t)64 << 20)), max_img);
-        RPH_TRY(P.reserve_recon(0, recon, P.slot[0].stream));
-        if (need > chunk_bytes) RPH_TRY(P.reserve_recon(1, recon, P.slot[1].stream));
-    }
-    const size_t n = idx.size();
-    int k = 0;
-    for (size_t first = 0; first < n; k++) {
-        size_t last = first, blocks = 0, file_bytes = 0;
-        while (last < n) {
-            const Job &j = jobs[idx[last]];
-            const size_t nb = (size_t)j.frame.total_blocks;
-            if (last > first && (blocks + nb) * 128 > chunk_bytes) break;
-            blocks += nb;
-            file_bytes += align_up(j.len + 160, 16);
-            last++;
-        }
-        if (blocks * 128 > region) {  // one image larger than a whole region: the host path takes it
-            leftover.push_back(idx[first]);
-            first = last;
-            k--;
-            continue;
-        }
-        const int b = k & 1;
-        RPH_TRY(finish(b));  // the lane is free again once its previous chunk (two chunks back) has delivered its results
-        Slot &S = P.slot[b];
-        hipStream_t s = S.stream;
-        int16_t *d_coef = P.d_coef + (single ? 0 : (size_t)b * (region / 2));
-        const size_t m = last - first;
-        RPH_TRY(S.reserve_res(m));
-        RPH_TRY(S.stream_bytes.reserve(file_bytes + 64));
-        // ---- streams and scan plans (host threads: memchr + memcpy)
-        const double t0 = now_ms();
-        {
-            size_t off = 0;
-            uint64_t fb = 0;
-            for (size_t i = first; i < last; i++) {
-                Job &j = jobs[idx[i]];
-                j.stream_off = off;
-                off += align_up(j.len + 160, 16);
-                j.first_block = fb;
-                fb += j.frame.total_blocks;
-            }
-        }
-        TableStore store;
-        std::vector<HImage> himgs(m);
-        parallel_for(first, last, threads, [&](size_t i) {
-            Job &j = jobs[idx[i]];
-            HImage &hi = himgs[i - first];
-            memset(&hi, 0, sizeof hi);
-            j.status = rphj::prepare_stream(j.data, j.len, j.frame, j.plan, S.stream_bytes.h + j.stream_off, align_up(j.len + 160, 16), &j.stream_used, &TableStore::intern, &store, &j.marks);
-            if (j.status != RPH_OK) return;
-            const rphj::Frame &f = j.frame;
-            hi.first_block = j.first_block;
-            hi.stream_base = j.stream_off;
-            hi.mcus_x = f.mcus_x;
-            hi.mcus_y = f.mcus_y;
-            hi.n_scans = (uint32_t)j.plan.n_scans;
-            hi.ncomp = (uint32_t)f.ncomp;
-            for (int c = 0; c < f.ncomp; c++) {
-                const rphj::Comp &kc = f.comp[c];
-                hi.comp[c] = HComp{kc.blocks_w, kc.real_bw, kc.real_bh, (uint32_t)kc.first_block, kc.H, kc.V};
-            }
-            for (int q = 0; q < j.plan.n_scans; q++) {
-                const rphj::ScanPlan &sp = j.plan.scan[q];
-                HScan &hs = hi.scan[q];
-                hs.off = sp.stream_off;
-                hs.len = sp.stream_len;
-                hs.restart_interval = sp.restart_interval;
-                hs.ns = sp.ns;
-                for (int c = 0; c < sp.ns; c++) {
-                    hs.ci[c] = sp.ci[c];
-                    hs.dc[c] = sp.dc[c];
-                    hs.ac[c] = sp.ac[c];
-                }
-            }
-        });
-        const double t_prep = now_ms();
-        RPH_JPEG_STAMP("lane %d: chunk %d prepared (%zu files)", b, k, m);
-        // files the walk does not take (more than four scans) go back to the host decoder; they keep their place in the chunk as holes.
-        // Work items: one per restart interval where a file has them, else one per file; lanes take them longest first.
-        std::vector<HItem> items;
-        std::vector<uint32_t> item_len;
-        items.reserve(m);
-        for (size_t i = first; i < last; i++) {
-            Job &j = jobs[idx[i]];
-            if (j.status == RPH_ERR_UNSUPPORTED || j.status == RPH_ERR_CAPACITY) leftover.push_back(idx[i]);
-            if (j.status != RPH_OK) continue;
-            const uint32_t r = (uint32_t)(i - first);
-            if (j.marks.empty()) {
-                items.push_back(HItem{r, HITEM_ALL_SCANS, 0, 0, 0});
-                item_len.push_back((uint32_t)std::min<size_t>(j.len, 0xFFFFFFFFu));
-                continue;
-            }
-            const rphj::ScanPlan &sp = j.plan.scan[0];
-            const rphj::Frame &f = j.frame;
-            const uint64_t mcus = sp.ns == 1 ? (uint64_t)f.comp[sp.ci[0]].real_bw * f.comp[sp.ci[0]].real_bh : (uint64_t)f.mcus_x * f.mcus_y;
-            const uint32_t n_int = (uint32_t)j.marks.size() + 1;
-            for (uint32_t k = 0; k < n_int; k++) {
-                const uint32_t off = k ? j.marks[k - 1] : 0, end = k + 1 < n_int ? j.marks[k] : sp.stream_len;
-                const uint64_t m_first = (uint64_t)k * sp.restart_interval;
-                items.push_back(HItem{r, 0, (uint32_t)m_first, (uint32_t)std::min<uint64_t>(sp.restart_interval, mcus - m_first), off});
-                item_len.push_back(end > off ? end - off : 0);
-            }
-        }
-        std::vector<uint32_t> order(items.size());
-        for (uint32_t t = 0; t < order.size(); t++) order[t] = t;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return item_len[a] > item_len[b]; });
-        const std::vector<rphj::DeviceLut> &luts = store.luts;
-        // ---- meta buffer: reconstruction descriptors | HImage | order | tables
-        const size_t recon_bytes = m * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128);
-        const size_t off_himg = align_up(recon_bytes, 16), off_items = off_himg + m * sizeof(HImage), off_order = off_items + items.size() * sizeof(HItem),
-                     off_luts = align_up(off_order + order.size() * 4, 16), meta_bytes = off_luts + luts.size() * sizeof(rphj::DeviceLut);
-        RPH_TRY(S.meta.reserve(meta_bytes));
-        ChunkDesc D;
-        std::vector<size_t> subs;
-        RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, false, P.recon_coef_bytes[b], S.meta.h, 0, D, subs));
-        memcpy(S.meta.h + off_himg, himgs.data(), m * sizeof(HImage));
-        memcpy(S.meta.h + off_items, items.data(), items.size() * sizeof(HItem));
-        memcpy(S.meta.h + off_order, order.data(), order.size() * 4);
-        if (!luts.empty()) memcpy(S.meta.h + off_luts, luts.data(), luts.size() * sizeof(rphj::DeviceLut));
-        // ---- device: streams up, zeroed coefficients, the walk, then reconstruction + hashing sub-batch by sub-batch
-        const double t_desc = now_ms();
-        const bool tr = trace_on();  // RPH_JPEG_TRACE: synchronise after every phase and print where the time goes (stderr)
-        double t_up = 0, t_zero = 0, t_walk = 0, t_rec = 0;
-        auto lap = [&](double &t) {
-            if (tr) {
-                (void)hipStreamSynchronize(s);
-                t = now_ms();
-            }
-        };
-        ResView R(S.res.d, S.res_images);
-        RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
-        if (!order.empty()) {
-            RPH_HIP_CHECK(hipMemcpyAsync(S.stream_bytes.d, S.stream_bytes.h, file_bytes + 64, hipMemcpyHostToDevice, s));
-            RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, meta_bytes, hipMemcpyHostToDevice, s));
-            lap(t_up);
-            RPH_HIP_CHECK(hipMemsetAsync(d_coef, 0, blocks * 128, s));
-            lap(t_zero);
-            {
-                const dim3 grid(((uint32_t)order.size() + 63) / 64);
-                const HImage *d_himg = reinterpret_cast<const HImage *>(S.meta.d + off_himg);
-                const HItem *d_items = reinterpret_cast<const HItem *>(S.meta.d + off_items);
-                const uint32_t *d_order = reinterpret_cast<const uint32_t *>(S.meta.d + off_order);
-                const rphj::DeviceLut *d_luts = reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts);
-                if (luts.size() <= (size_t)HUFF_LDS_TABLES)
-                    hipLaunchKernelGGL(jpeg_huff_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, s, S.stream_bytes.d, d_himg, d_items, d_order, (uint32_t)order.size(), d_luts, (uint32_t)luts.size(),
-                                       d_coef, R.status);
-                else
-                    hipLaunchKernelGGL(jpeg_huff_kernel<0>, grid, dim3(64), 0, s, S.stream_bytes.d, d_himg, d_items, d_order, (uint32_t)order.size(), d_luts, (uint32_t)luts.size(), d_coef,
-                                       R.status);
-            }
-            RPH_HIP_CHECK(hipGetLastError());
-            lap(t_walk);
-            for (size_t q = 0; q < subs.size(); q++) {
-                const size_t r0 = subs[q], r1 = q + 1 < subs.size() ? subs[q + 1] : m;
-                RPH_TRY(reconstruct_and_hash(ctx, P, b, S, jobs, idx, first, D, r0, r1, d_coef, flavour, out, s));
-            }
-            lap(t_rec);
-            if (tr)
-                fprintf(stderr, "[rph_jpeg] chunk of %zu files in %zu lanes (%.1f MB of entropy bytes, %.2f GB of coefficients, %zu tables, %zu sub-batches): prepare %.1f ms, "
-                                "descriptors %.1f ms, upload %.1f ms, zero %.1f ms, walk %.1f ms, reconstruct + hash %.1f ms\n",
-                        m, order.size(), file_bytes / 1e6, blocks * 128 / 1e9, luts.size(), subs.size(), t_prep - t0, t_desc - t_prep, t_up - t_desc, t_zero - t_up, t_walk - t_zero, t_rec - t_walk);
-        }
-        RPH_HIP_CHECK(hipEventRecord(S.done, s));
-        RPH_JPEG_STAMP("lane %d: chunk %d enqueued", b, k);
-        pend[b].active = true;
-        pend[b].first = first;
-        pend[b].last = last;
-        first = last;
-    }
-    RPH_TRY(finish(k & 1));
-    RPH_TRY(finish((k + 1) & 1));
-    // files handed to the host decoder start over there
-    for (uint32_t g : leftover) jobs[g].status = RPH_OK;
-    return RPH_OK;
-}
-
-int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint32_t n, int flavour, uint32_t n_threads, Outputs out, Jobs *prepared = nullptr)
-{
-    if (flavour != RPH_JPEG_ZUNE && flavour != RPH_JPEG_LIBJPEG) {
-        rph_set_error("rph_jpeg: unknown flavour %d", flavour);
-        return RPH_ERR_INVALID_ARG;
-    }
-    std::lock_guard<std::mutex> lock(ctx->jpeg_mu);
-    RPH_HIP_CHECK(hipSetDevice(ctx->device));
-    if (!ctx->jpeg) ctx->jpeg = new JpegPipe();
-    JpegPipe &P = *static_cast<JpegPipe *>(ctx->jpeg);
-    unsigned threads = n_threads ? n_threads : default_threads();
-    threads = std::min(threads, 256u);
-
-    g_trace_t0 = now_ms();
-    RPH_JPEG_STAMP("call: %u files", n);
-    Jobs local(prepared ? 0 : n);  // (first-touching the storage from the parsing threads instead is 5x slower: page faults under contention)
-    Jobs &jobs = prepared ? *prepared : local;
-    if (!prepared)
-        parallel_for(0, n, n >= 1024 ? threads : 1, [&](size_t i) {
-            Job &j = jobs[i];
-            j.data = data[i];
-            j.len = len[i];
-            j.status = (j.data && j.len) ? rphj::parse_frame(j.data, j.len, j.frame) : RPH_ERR_INVALID_ARG;
-            if (j.status == RPH_OK && j.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) j.status = RPH_ERR_UNSUPPORTED;
-        });
-    RPH_JPEG_STAMP("frames parsed");
-    // which files walk their Huffman streams on the device: sequential ones, when the batch is large enough to fill lanes
-    std::vector<uint32_t> host_idx, dev_idx;
-    for (uint32_t i = 0; i < n; i++) {
-        const Job &j = jobs[i];
-        if (j.status == RPH_OK && !j.frame.progressive && ctx->jpeg_entropy != 0 && out.want_hash && !prepared)
-            dev_idx.push_back(i);
-        else
-            host_idx.push_back(i);
-    }
-    // automatic mode: the device walk pays when it has lanes to fill -- one per file, or one per restart interval where the frame
-    // header announces them (a few dozen photos with restart markers are thousands of short streams)
-    uint64_t lanes = 0;
-    for (uint32_t i : dev_idx) {
-        const rphj::Frame &f = jobs[i].frame;
-        lanes += f.restart_interval ? ((uint64_t)f.mcus_x * f.mcus_y + f.restart_interval - 1) / f.restart_interval : 1;
-    }
-    if (ctx->jpeg_entropy == 2 && lanes < DEVICE_ENTROPY_MIN_FILES) {
-        host_idx.clear();
-        for (uint32_t i = 0; i < n; i++) host_idx.push_back(i);
-        dev_idx.clear();
-    }
-    if (!dev_idx.empty()) {
-        std::vector<uint32_t> leftover;
-        RPH_TRY(run_device_entropy(ctx, P, jobs, dev_idx, flavour, threads, out, leftover));
-        host_idx.insert(host_idx.end(), leftover.begin(), leftover.end());
-        std::sort(host_idx.begin(), host_idx.end());
-    }
-    if (!host_idx.empty()) RPH_TRY(run_host_entropy(ctx, P, jobs, host_idx, flavour, threads, out));
-    RPH_JPEG_STAMP("all chunks done");
-    int worst = RPH_OK;
-    for (uint32_t i = 0; i < n; i++) {
-        if (out.status) out.status[i] = jobs[i].status;
-        if (jobs[i].status != RPH_OK) worst = jobs[i].status;
-    }
-    if (n == 1 && worst != RPH_OK) rph_set_error("rph_jpeg: not decodable (status %d)", worst);
-    return n == 1 ? worst : RPH_OK;  // a batch reports per image (status / valid); one image reports itself
-}
-
-}  // namespace
-
-void rph_jpeg_forget_threads(rph_ctx *ctx)  // rph_shutdown: no caller is inside the library any more
-{
-    for (void *p : ctx->jpeg_thread_buffers) (void)hipHostFree(p);
-    ctx->jpeg_thread_buffers.clear();
-}
-
-void rph_jpeg_forget(rph_ctx *ctx)
-{
-    if (ctx->jpeg) {
-        JpegPipe *P = static_cast<JpegPipe *>(ctx->jpeg);
-        P->release();
-        delete P;
-        ctx->jpeg = nullptr;
-    }
-}
-
-extern "C" {
-
-int rph_jpeg_info(const uint8_t *data, size_t len, uint32_t *w, uint32_t *h, uint32_t *channels)
-{
-    return rph_guarded("rph_jpeg_info", [&]() -> int {
-        if (!data || !w || !h || !channels) {
-            rph_set_error("rph_jpeg_info: null argument");
-            return RPH_ERR_INVALID_ARG;
-        }
-        rphj::Frame f;
-        const int rc = rphj::parse_frame(data, len, f);
-        if (rc != RPH_OK) {
-            rph_set_error("rph_jpeg_info: %s", rc == RPH_ERR_UNSUPPORTED ? "unsupported kind of JPEG" : "not a JPEG stream");
-            return rc;
-        }
-        *w = f.w;
-        *h = f.h;
-        *channels = (uint32_t)f.ncomp;
-        return RPH_OK;
-    });
-}
-
-int rph_jpeg_coefficients(const uint8_t *data, size_t len, uint32_t *geometry, uint16_t *qt, int16_t *coef, size_t cap_blocks, uint64_t *total_blocks)
-{
-    return rph_guarded("rph_jpeg_coefficients", [&]() -> int {
-        if (!data || !geometry || !qt || !total_blocks) {
-            rph_set_error("rph_jpeg_coefficients: null argument");
-            return RPH_ERR_INVALID_ARG;
-        }
-        rphj::Frame f;
-        int rc = rphj::parse_frame(data, len, f);
-        if (rc != RPH_OK) return rc;
-        *total_blocks = f.total_blocks;
-        std::vector<int16_t> tmp;
-        int16_t *dst = coef;
-        if (!coef) {
-            tmp.resize((size_t)f.total_blocks * 64);
-            dst = tmp.data();
-        } else if (cap_blocks < f.total_blocks) {
-            rph_set_error("rph_jpeg_coefficients: %llu blocks, capacity %zu", (unsigned long long)f.total_blocks, cap_blocks);
-            return RPH_ERR_CAPACITY;
-        }
-        rc = rphj::decode_coefficients(data, len, f, dst);
-        if (rc != RPH_OK) {
-            rph_set_error("rph_jpeg_coefficients: entropy decoding failed (status %d)", rc);
-            return rc;
-        }
-        for (int c = 0; c < f.ncomp; c++) {
-            const rphj::Comp &k = f.comp[c];
-            uint32_t *g = geometry + 8 * c;
-            g[0] = k.blocks_w, g[1] = k.blocks_h, g[2] = k.H, g[3] = k.V, g[4] = k.tq, g[5] = k.samp_w, g[6] = k.samp_h, g[7] = (uint32_t)k.first_block;
-        }
-        for (int t = 0; t < 4; t++) {
-            if (f.qt_present[t])
-                memcpy(qt + 64 * t, f.qt[t], 128);
-            else
-                memset(qt + 64 * t, 0, 128);
-        }
-        return RPH_OK;
-    });
-}
-
-int rph_jpeg_release(rph_ctx *ctx)
-{
-    if (!ctx) {
-        rph_set_error("rph_jpeg_release: null argument");
-        return RPH_ERR_INVALID_ARG;
-    }
-    std::lock_guard<std::mutex> lock(ctx->jpeg_mu);
-    RPH_HIP_CHECK(hipSetDevice(ctx->device));
-    rph_jpeg_forget(ctx);
-    return RPH_OK;
-}
-
-int rph_jpeg_set_entropy(rph_ctx *ctx, int where)
-{
-    if (!ctx || where < 0 || where > 2) {
-        rph_set_error("rph_jpeg_set_entropy: invalid argument");
-        return RPH_ERR_INVALID_ARG;
-    }
-    std::lock_guard<std::mutex> lock(ctx->jpeg_mu);
-    ctx->jpeg_entropy = where;
-    return RPH_OK;
-}
-
-int rph_jpeg_decode(rph_ctx *ctx, const uint8_t *data, size_t len, int flavour, uint8_t *pixels_out)
-{
-    return rph_guarded("rph_jpeg_decode", [&]() -> int {
-        if (!ctx || !data || !pixels_out) {
-            rph_set_error("rph_jpeg_decode: null argument");
-            return RPH_ERR_INVALID_ARG;
-        }
-        Outputs o;
-        o.pixels = pixels_out;
-        o.want_hash = false;
-        return run_batch(ctx, &data, &len, 1, flavour, 1, o);
-    });
-}
-
-// One file per call from many threads (the reference's scan loop: load_image_fast + generate_pdq_features on every rayon worker,
-// scanner.rs:1202, :1410).  Callers that arrive while a batch is on its way wait and leave together as the next batch, which one of
-// them (the leader) runs through the reconstruction + hashing stages of rph_jpeg_pdq_hash_batch.  Every caller undoes the entropy
-// coding of its own file first, on its own core, into a pinned buffer of its own that the copy engine reads directly.
-namespace {
-struct OneRequest {
-    const uint8_t *data;
-    size_t len;
-    int flavour;
-    rphj::Frame frame;
-    const int16_t *coef;  // the caller's pinned buffer, decoded by the caller
-    uint8_t hash[32];
-    float quality, coeffs[256];
-    uint8_t valid;
-    int32_t status;
-    bool want_coeffs, done;
-};
-// One pinned coefficient buffer per calling thread (a scan worker decodes thousands of files into it).  It belongs to the context:
-// rph_shutdown frees it (a thread-local destructor would call into the HIP runtime at thread or process exit, possibly after the
-// runtime is gone); `serial` tells a later context at the same address from the one that owned the buffer.
-struct ThreadPinned {
-    int16_t *p = nullptr;
-    size_t cap = 0;
-    rph_ctx *owner = nullptr;
-    uint64_t serial = 0;
-};
-thread_local ThreadPinned tls_coef;
-}  // namespace
-
-int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int flavour, uint8_t *hash32_out, float *quality_out, float *coeffs_out, uint8_t *valid_out)
-{
-    return rph_guarded("rph_jpeg_pdq_hash_one", [&]() -> int {
-        if (!ctx || !data || !hash32_out || (flavour != RPH_JPEG_ZUNE && flavour != RPH_JPEG_LIBJPEG)) {
-            rph_set_error("rph_jpeg_pdq_hash_one: invalid argument");
-            return RPH_ERR_INVALID_ARG;
-        }
-        // ---- this thread: frame header and entropy decoding into its own pinned buffer (all callers do this side by side)
-        OneRequest me;
-        me.data = data, me.len = len, me.flavour = flavour, me.want_coeffs = coeffs_out != nullptr, me.done = false, me.valid = 0, me.quality = 0.f, me.coef = nullptr;
-        me.status = rphj::parse_frame(data, len, me.frame);
-        if (me.status == RPH_OK && me.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) me.status = RPH_ERR_UNSUPPORTED;
-        if (me.status == RPH_OK) {
-            const size_t need = (size_t)me.frame.total_blocks * 128;
-            if (tls_coef.owner != ctx || tls_coef.serial != ctx->serial) tls_coef = ThreadPinned();  // another (or an earlier) context's buffer is not ours to use
-            if (tls_coef.cap < need) {
-                RPH_HIP_CHECK(hipSetDevice(ctx->device));
-                std::lock_guard<std::mutex> reg(ctx->jpeg_qmu);
-                if (tls_coef.p) {
-                    auto &v = ctx->jpeg_thread_buffers;
-                    v.erase(std::remove(v.begin(), v.end(), (void *)tls_coef.p), v.end());
-                    (void)hipHostFree(tls_coef.p);
-                }
-                tls_coef = ThreadPinned();
-                const size_t cap = align_up(need + need / 2, 1 << 20);
-                RPH_HIP_CHECK(hipHostMalloc((void **)&tls_coef.p, cap));
-                tls_coef.cap = cap;
-                tls_coef.owner = ctx;
-                tls_coef.serial = ctx->serial;
-                ctx->jpeg_thread_buffers.push_back(tls_coef.p);
-            }
-            me.status = rphj::decode_coefficients(data, len, me.frame, tls_coef.p);
-            me.coef = tls_coef.p;
-        }
-        if (me.status != RPH_OK) {
-            memset(hash32_out, 0, 32);
-            if (quality_out) *quality_out = 0.f;
-            if (coeffs_out) memset(coeffs_out, 0, 1024);
-            if (valid_out) *valid_out = 0;
-            rph_set_error("rph_jpeg_pdq_hash_one: not decodable here (status %d)", me.status);
-            return me.status;
-        }
-        // ---- the device part: with everyone else who is waiting, as one batch, run by one of them
-        std::unique_lock<std::mutex> lk(ctx->jpeg_qmu);
-        ctx->jpeg_waiting.push_back(&me);
-        while (!me.done) {
-            if (ctx->jpeg_leader) {
-                ctx->jpeg_qcv.wait(lk);
-                continue;
-            }
-            ctx->jpeg_leader = true;
-            std::vector<void *> batch;
-            batch.swap(ctx->jpeg_waiting);
-            lk.unlock();
-            for (int fl = 0; fl < 2; fl++) {  // (callers may ask for different arithmetic flavours: one pass each)
-                std::vector<OneRequest *> reqs;
-                for (void *p : batch)
-                    if (static_cast<OneRequest *>(p)->flavour == fl) reqs.push_back(static_cast<OneRequest *>(p));
-                if (reqs.empty()) continue;
-                const uint32_t n = (uint32_t)reqs.size();
-                int rc = RPH_OK;
-                std::vector<uint8_t> hashes((size_t)n * 32), valid(n);
-                std::vector<float> quality(n), coeffs;
-                std::vector<int32_t> status(n);
-                try {
-                    bool any_coeffs = false;
-                    Jobs jobs(n);
-                    for (uint32_t i = 0; i < n; i++) {
-                        jobs[i].data = reqs[i]->data, jobs[i].len = reqs[i]->len, jobs[i].frame = reqs[i]->frame, jobs[i].pre = reqs[i]->coef;
-                        any_coeffs |= reqs[i]->want_coeffs;
-                    }
-                    coeffs.resize(any_coeffs ? (size_t)n * 256 : 0);
-                    Outputs o;
-                    o.hash = hashes.data(), o.quality = quality.data(), o.coeffs = any_coeffs ? coeffs.data() : nullptr, o.valid = valid.data(), o.status = status.data();
-                    rc = run_batch(ctx, nullptr, nullptr, n, fl, 1, o, &jobs);
-                } catch (...) {
-                    rc = RPH_ERR_OOM;
-                }
-                for (uint32_t i = 0; i < n; i++) {
-                    OneRequest &r = *reqs[i];
-                    r.status = (rc != RPH_OK && status[i] == RPH_OK) ? rc : status[i];  // a failure of the call itself fails all of its files
-                    memcpy(r.hash, &hashes[(size_t)i * 32], 32);
-                    r.quality = quality[i];
-                    r.valid = r.status == RPH_OK ? valid[i] : 0;
-                    if (r.want_coeffs && !coeffs.empty()) memcpy(r.coeffs, &coeffs[(size_t)i * 256], 1024);
-                }
-            }
-            lk.lock();
-            for (void *p : batch) static_cast<OneRequest *>(p)->done = true;
-            ctx->jpeg_leader = false;
-            ctx->jpeg_qcv.notify_all();
-        }
-        lk.unlock();
-        memcpy(hash32_out, me.hash, 32);
-        if (quality_out) *quality_out = me.quality;
-        if (coeffs_out) memcpy(coeffs_out, me.coeffs, 1024);
-        if (valid_out) *valid_out = me.valid;
-        if (me.status != RPH_OK) rph_set_error("rph_jpeg_pdq_hash_one: failed (status %d)", me.status);
-        return me.status;
-    });
-}
-
-int rph_jpeg_pdq_hash_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint32_t n, int flavour, uint32_t n_threads, uint8_t *hash32_out,
-                            float *quality_out, float *coeffs_out, uint8_t *dihedral_out, uint8_t *valid_out, int32_t *status_out)
-{
-    return rph_guarded("rph_jpeg_pdq_hash_batch", [&]() -> int {
-        if (!ctx || (n && (!data || !len)) || !hash32_out) {
-            rph_set_error("rph_jpeg_pdq_hash_batch: null argument");
-            return RPH_ERR_INVALID_ARG;
-        }
-        if (n == 0) return RPH_OK;
-        Outputs o;
-        o.hash = hash32_out;
-        o.quality = quality_out;
-        o.coeffs = coeffs_out;
-        o.dihedral = dihedral_out;
-        o.valid = valid_out;
-        o.status = status_out;
-        return run_batch(ctx, data, len, n, flavour, n_threads, o);
-    });
-}
-
-}  // extern "C"

@@ -53,7 +53,7 @@ struct rph_ctx {
     // 512x512 RGB8: 0 = always generic; 1 / 2 = fused one-wave-per-image kernel (64- / 128-px strips); 3 = fused low-latency kernel (eight
     // waves per image); 4 = automatic: low-latency below 768 images per call, one-wave-per-image (64-px strips) from there
     int pdq_kernel = 4;
-    // JPEG path (jpeg_kernels.hip): two chunk slots (pinned staging, device buffers, stream), kept across calls; one batch call at a time
+    // JPEG path (jpeg_pipeline.cpp): two chunk slots (pinned staging, device buffers, stream), kept across calls; one batch call at a time
     std::mutex jpeg_mu;
     void *jpeg = nullptr;
     // where the Huffman streams of sequential files are decoded: 0 = host threads, 1 = device (one image per lane), 2 = automatic
@@ -138,7 +138,7 @@ int rph_pdq_hash_batch_keep(rph_ctx *ctx, const uint8_t *px, uint32_t n, uint32_
 void rph_batcher_forget(rph_ctx *ctx);
 // resize_kernels.hip
 void rph_resize_forget(rph_ctx *ctx);
-// jpeg_kernels.hip
+// jpeg_pipeline.cpp
 void rph_jpeg_forget(rph_ctx *ctx);
 void rph_jpeg_forget_threads(rph_ctx *ctx);
 
