@@ -378,6 +378,11 @@ int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int fla
 #define RPH_JPEG_ENTROPY_DEVICE 1
 #define RPH_JPEG_ENTROPY_AUTO 2
 int rph_jpeg_set_entropy(rph_ctx *ctx, int where);
+/* Tuning of the device walk for streams WITHOUT restart markers: from min_stream_bytes of entropy-coded data (default 65536) a
+ * stream is cut into segments of segment_bytes (default 1024; a multiple of 4 in 64 .. 65536; 0 = never) that find their
+ * entry points on the device (Huffman streams re-synchronise; the chain of entries is verified, a file that does not verify is
+ * walked by one lane) and are then walked side by side.  Same results whatever the setting. */
+int rph_jpeg_set_segments(rph_ctx *ctx, uint32_t min_stream_bytes, uint32_t segment_bytes);
 /* The JPEG path keeps its staging and device buffers in the context between calls (for a large call up to half of the free device
  * memory for the coefficients of the files in flight); this returns them.  The next call allocates again. */
 int rph_jpeg_release(rph_ctx *ctx);

@@ -110,6 +110,7 @@ SIGNATURES = {
     "rph_jpeg_decode": (C.c_int, [_vp, C.c_char_p, _sz, C.c_int, _u8p]),
     "rph_jpeg_pdq_hash_one": (C.c_int, [_vp, C.c_char_p, _sz, C.c_int, _u8p, _f32p, _f32p, _u8p]),
     "rph_jpeg_set_entropy": (C.c_int, [_vp, C.c_int]),
+    "rph_jpeg_set_segments": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "rph_jpeg_release": (C.c_int, [_vp]),
     "rph_jpeg_pdq_hash_batch": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_uint32, C.c_int, C.c_uint32, _u8p, _f32p, _f32p,
                                           _u8p, _u8p, _i32p]),

@@ -48,6 +48,33 @@ struct HImage {
 constexpr uint32_t HITEM_ALL_SCANS = 0xFFFFFFFFu;
 struct HItem {
     uint32_t image, scan, mcu_first, mcu_count, stream_off;
+    uint32_t bit_skip;  // bits to drop behind stream_off before the first symbol (segments of a stream without markers begin mid-byte)
+    int32_t dc[3];      // predictions at the item's first MCU, in the scan's component order (0 at a restart interval)
+};
+
+// ---- a stream WITHOUT restart markers, cut into segments of SEG_BYTES that are walked side by side (jpeg_sync_kernel) ------------------
+// A lane cannot know where a symbol begins in the middle of a stream, but Huffman streams re-synchronise: a lane that starts at a
+// segment boundary in an assumed state (an MCU begins here) soon parses the same symbols as the true decoder.  Round 0: every lane
+// decodes from its segment boundary, marks where it saw MCUs begin inside its segment (bitmap) and reports the first MCU start behind
+// its segment (`out`).  Validation rounds: the entry of segment t is the `out` of segment t - 1; if the lane saw an MCU begin exactly
+// there its results stand, otherwise it decodes again from the entry.  The count pass decodes every segment from its entry once more
+// (MCUs and DC sums per segment, and `out` again); the prefix kernel then checks entry[t] == out[t - 1] along each file -- true for
+// segment 0 by construction, hence for all of them -- and turns the segments into walk items (first MCU, DC predictions); a file
+// that did not settle is walked by one lane as before.  Nothing here is trusted: the chain is verified, or not used.
+constexpr uint32_t SEG_NONE = 0xFFFFFFFFu;
+struct SegFile {           // one per segmented file of the chunk
+    uint32_t image;        // index of its HImage
+    uint32_t first_seg, n_segs;
+    uint32_t first_item;   // its walk items: first_item .. first_item + n_segs - 1
+    uint32_t total_mcus;
+};
+struct SegState {          // one per segment
+    uint32_t entry;        // bit position (from the scan's first bit) of the first MCU that begins in or behind the segment; SEG_NONE: unknown
+    uint32_t out;          // first MCU start at or behind the end of the segment, as this lane's last decode saw it
+    uint32_t count;        // MCUs that begin in [entry, out)
+    int32_t dc[3];         // sum of their DC differences per component of the scan
+    uint32_t from;         // the position the lane's last decode started from (its bitmap describes that decode)
+    uint32_t out_check;    // count pass: `out` as decoded from `entry` (must equal out)
 };
 
 
@@ -57,5 +84,11 @@ constexpr int HUFF_LDS_TABLES = 8;  // the walk keeps the chunk's Huffman tables
 int rph_jpeg_launch_idct(int flavour, uint32_t max_blocks, uint32_t n_planes, hipStream_t stream, const int16_t *d_coef, const uint16_t *d_tables, const JPlane *d_planes,
                          uint8_t *d_samples);
 int rph_jpeg_launch_color(int flavour, uint32_t max_groups, uint32_t n_images, hipStream_t stream, const uint8_t *d_samples, const JImage *d_images, uint8_t *d_pixels);
-int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const HItem *d_items, const uint32_t *d_order, uint32_t n_items,
-                         const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status);
+// d_order: the first n_ordered items in the order the lanes take them (longest first); items n_ordered .. n_items - 1 are taken as they lie
+int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const HItem *d_items, const uint32_t *d_order, uint32_t n_ordered,
+                         uint32_t n_items, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status);
+// Segment synchronisation of the files in d_files (see above): round 0, `rounds` validation rounds, the count pass and the prefix
+// kernel, which writes the files' walk items (d_items[first_item ..]) -- n_segs of them per file, or one whole-file item and empty ones
+// when the file's chain did not verify.  d_bitmap: seg_bytes + 12 bytes per segment (marks, two `out` slots, the segment -> file map).
+int rph_jpeg_launch_segments(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const SegFile *d_files, uint32_t n_files, SegState *d_segs,
+                             uint32_t n_segs, uint32_t seg_bytes, uint32_t *d_bitmap, int rounds, const rphj::DeviceLut *d_luts, HItem *d_items);

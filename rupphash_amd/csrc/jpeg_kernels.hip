@@ -339,8 +339,8 @@ __device__ __forceinline__ T sel3(uint32_t i, T a, T b, T c)
 // time of a cached global read.
 template <int LDS_TABLES>
 __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const HItem *__restrict__ items,
-                                                       const uint32_t *__restrict__ order, uint32_t n, const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts,
-                                                       int16_t *__restrict__ coef, uint8_t *__restrict__ status)
+                                                       const uint32_t *__restrict__ order, uint32_t n_ordered, uint32_t n, const rphj::DeviceLut *__restrict__ g_luts,
+                                                       uint32_t n_luts, int16_t *__restrict__ coef, uint8_t *__restrict__ status)
 {
     __shared__ uint8_t zz[80];
     __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
     __syncthreads();
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
     if (slot >= n) return;
-    const HItem item = items[order[slot]];
+    const HItem item = items[slot < n_ordered ? order[slot] : slot];  // the first n_ordered items longest first; the segments' items behind them as they lie
     const uint32_t ii = item.image;
     const HImage *im = imgs + ii;
     const uint64_t img_fb = im->first_block;
@@ -394,6 +394,10 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
         auto be64 = [](W2 v) -> uint64_t { return ((uint64_t)__builtin_bswap32(v.x) << 32) | __builtin_bswap32(v.y); };
         uint64_t acc = (uint64_t)(__builtin_bswap32(*reinterpret_cast<const uint32_t *>(sbase)) << (8 * lead)) << 32;
         int nb = 32 - 8 * (int)lead;
+        if (part) {  // a segment of a stream without markers begins mid-byte (at least 8 bits are in the accumulator)
+            acc <<= item.bit_skip;
+            nb -= (int)item.bit_skip;
+        }
         uint64_t q0 = be64(load8(4));
         W2 q1 = load8(12);  // kept as loaded: its bytes are swapped when it becomes q0, a word later, so nothing waits on the load now
         uint32_t q0n = 64, woff = 20;
@@ -402,7 +406,7 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
         uint32_t i = 0, h = 0, v = 0, mx = MX ? m0 % MX : 0, my = MX ? m0 / MX : 0, k = 0, until = ri, left = part ? item.mcu_count : 0xFFFFFFFFu;
         uint32_t Hc = H0, Vc = V0, BWc = BW0, FBc = FB0;
         const rphj::DeviceLut *DCc = D0, *ACc = A0;
-        int p0 = 0, p1 = 0, p2 = 0;
+        int p0 = part ? item.dc[0] : 0, p1 = part ? item.dc[1] : 0, p2 = part ? item.dc[2] : 0;
         bool is_dc = true, done = MX == 0 || MY == 0 || my >= MY || left == 0;
         uint64_t base = (img_fb + FBc + (uint64_t)(my * Vc) * BWc + mx * Hc) * 64;
         for (uint64_t it = 0; !done && it < max_it; it++) {
@@ -503,6 +507,221 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Segments of a stream without restart markers (jpeg_device.h): one lane per segment.  mode 0: decode from the segment boundary as if an
+// MCU began there, mark the MCU starts seen inside the segment, report the first one behind it.  mode 1 (validation round `round`): the
+// entry is the predecessor's `out` of the previous round; if this lane's last decode started there or saw an MCU begin there, its
+// results stand, otherwise it decodes again from the entry.  mode 2: decode from the entry once more, counting MCUs and DC differences.
+// Nothing is written to the coefficient buffer here.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct SegOut2 {
+    uint32_t v[2];
+};
+__global__ void __launch_bounds__(64) jpeg_sync_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const SegFile *__restrict__ files,
+                                                       const uint32_t *__restrict__ seg_file, SegState *__restrict__ segs, SegOut2 *__restrict__ outs, uint32_t n_segs,
+                                                       uint32_t seg_bytes, uint32_t *__restrict__ bitmap, int mode, int round, const rphj::DeviceLut *__restrict__ luts)
+{
+    const uint32_t u = blockIdx.x * 64 + threadIdx.x;
+    if (u >= n_segs) return;
+    const SegFile F = files[seg_file[u]];
+    const uint32_t t = u - F.first_seg;
+    const HImage *im = imgs + F.image;
+    const HScan *S = &im->scan[0];
+    const uint32_t seg_bits = seg_bytes * 8, lo = t * seg_bits, hi = lo + seg_bits, end_bits = S->len * 8;
+    uint32_t *bm = bitmap + (size_t)u * (seg_bytes / 4);
+    SegState st = segs[u];
+    const int rd = (round + 1) & 1, wr = round & 1;  // validation round r reads the outs of round r - 1 (round 0 wrote slot 0)
+    uint32_t start;
+    if (mode == 0) {
+        start = lo;
+        st.entry = t == 0 ? 0 : SEG_NONE;
+    } else if (mode == 1) {
+        const uint32_t own = outs[u].v[rd];
+        const uint32_t e = t == 0 ? 0 : outs[u - 1].v[rd];
+        outs[u].v[wr] = own;  // unless decoded again below
+        if (e == SEG_NONE) return;  // the predecessor has nothing to say yet
+        st.entry = e;
+        if (e >= hi) {  // no MCU begins in this segment: pass the position on
+            st.from = e;
+            outs[u].v[wr] = e;
+            segs[u] = st;
+            return;
+        }
+        if (e == st.from || (st.from == lo && e >= lo && ((bm[(e - lo) >> 5] >> ((e - lo) & 31)) & 1u))) {  // the last decode went through e: its `out` stands
+            segs[u] = st;
+            return;
+        }
+        start = e;
+    } else {
+        st.count = 0;
+        st.dc[0] = st.dc[1] = st.dc[2] = 0;
+        st.out_check = st.entry;
+        if (st.entry == SEG_NONE || st.entry >= hi) {
+            segs[u] = st;
+            return;
+        }
+        start = st.entry;
+    }
+    // ---- decode from bit `start` of the scan, MCU after MCU, until one begins at or behind `hi`
+    const uint32_t ns = S->ns;
+    uint32_t H0, H1, H2, V0, V1, V2;
+    const rphj::DeviceLut *D0, *D1, *D2, *A0, *A1, *A2;
+    {
+        const HComp *c0 = &im->comp[S->ci[0]], *c1 = &im->comp[S->ci[ns > 1 ? 1 : 0]], *c2 = &im->comp[S->ci[ns > 2 ? 2 : 0]];
+        H0 = ns == 1 ? 1 : c0->H, V0 = ns == 1 ? 1 : c0->V, H1 = c1->H, V1 = c1->V, H2 = c2->H, V2 = c2->V;
+        D0 = luts + S->dc[0], A0 = luts + S->ac[0];
+        D1 = luts + S->dc[ns > 1 ? 1 : 0], A1 = luts + S->ac[ns > 1 ? 1 : 0];
+        D2 = luts + S->dc[ns > 2 ? 2 : 0], A2 = luts + S->ac[ns > 2 ? 2 : 0];
+    }
+    const uint32_t nblk0 = H0 * V0, nblk1 = ns > 1 ? H1 * V1 : 0, nblk2 = ns > 2 ? H2 * V2 : 0;
+    const uint8_t *sp = streams + im->stream_base + S->off + (start >> 3);
+    const uint32_t slen = S->len - ((start >> 3) < S->len ? (start >> 3) : S->len);
+    const uint32_t lead = (uint32_t)((uintptr_t)sp & 3);
+    const uint8_t *sbase = sp - lead;
+    const uint32_t limit = ((slen + lead + 3) & ~3u) + 8;
+    auto load8 = [&](uint32_t at) -> W2 { return *reinterpret_cast<const W2 *>(sbase + (at < limit ? at : limit)); };
+    auto be64 = [](W2 v) -> uint64_t { return ((uint64_t)__builtin_bswap32(v.x) << 32) | __builtin_bswap32(v.y); };
+    uint64_t acc = (uint64_t)(__builtin_bswap32(*reinterpret_cast<const uint32_t *>(sbase)) << (8 * lead)) << 32;
+    int nb = 32 - 8 * (int)lead;
+    acc <<= (start & 7);
+    nb -= (int)(start & 7);
+    uint64_t q0 = be64(load8(4));
+    W2 q1 = load8(12);
+    uint32_t q0n = 64, woff = 20;
+    uint32_t pos = start;       // bit position of the next unread bit
+    uint32_t i = 0, b = 0, k = 0;  // component of the MCU, block of the component, next coefficient index
+    uint32_t nblk = nblk0;
+    const rphj::DeviceLut *DCc = D0, *ACc = A0;
+    bool is_dc = true;
+    uint32_t count = 0, out = SEG_NONE;
+    int dc0 = 0, dc1 = 0, dc2 = 0;
+    if (mode == 0 && start >= lo) bm[(start - lo) >> 5] |= 1u << ((start - lo) & 31);  // (this lane's own words: no atomics needed)
+    const uint32_t max_it = seg_bits + 70000;  // every symbol takes at least one bit; an MCU is at most 10 blocks of 64 symbols of <= 32 bits
+    for (uint32_t it = 0; it < max_it; it++) {
+        if (nb < 32) {
+            acc |= (q0 >> 32) << (32 - nb);
+            nb += 32;
+            q0 <<= 32;
+            q0n -= 32;
+            if (q0n == 0) {
+                q0 = be64(q1);
+                q0n = 64;
+                q1 = load8(woff);
+                woff += 8;
+            }
+        }
+        const rphj::DeviceLut *L = is_dc ? DCc : ACc;
+        const uint32_t e = L->look[(uint32_t)(acc >> 54)];
+        uint32_t len = e >> 8, sym = e & 255;
+        if (e == 0) {
+            const int32_t win = (int32_t)(acc >> 48);
+            uint32_t l = 11;
+            while (l <= 16 && win >= L->maxcode[l]) l++;
+            if (l > 16) break;  // not a code: this decode was not synchronised (out stays SEG_NONE)
+            len = l;
+            sym = L->sym[(uint32_t)((win >> (16 - l)) + L->delta[l]) & 255];
+        }
+        acc <<= len;
+        nb -= (int)len;
+        const uint32_t sbits = is_dc ? sym : (sym & 15), r = is_dc ? 0 : (sym >> 4);
+        if (sbits > 15) break;
+        int val = 0;
+        if (sbits) {
+            const uint32_t raw = (uint32_t)(acc >> (64 - sbits));
+            acc <<= sbits;
+            nb -= (int)sbits;
+            val = raw < (1u << (sbits - 1)) ? (int)raw - (int)((1u << sbits) - 1) : (int)raw;
+        }
+        pos += len + sbits;
+        if (is_dc) {
+            dc0 += i == 0 ? val : 0;
+            dc1 += i == 1 ? val : 0;
+            dc2 += i == 2 ? val : 0;
+            k = 1;
+            is_dc = false;
+        } else if (sbits == 0) {
+            k = r == 15 ? k + 16 : 64;
+        } else {
+            k += r + 1;
+        }
+        if (k >= 64) {  // next block
+            is_dc = true;
+            k = 0;
+            if (++b == nblk) {
+                b = 0;
+                if (++i == ns) {  // the MCU is complete: the next one begins at `pos`
+                    i = 0;
+                    count++;
+                    if (pos >= hi || pos + 8 > end_bits) {  // (less than a byte left: the padding behind the last MCU)
+                        out = pos;
+                        break;
+                    }
+                    if (mode == 0 && pos >= lo) bm[(pos - lo) >> 5] |= 1u << ((pos - lo) & 31);
+                }
+                nblk = sel3(i, nblk0, nblk1, nblk2);
+                DCc = sel3(i, D0, D1, D2);
+                ACc = sel3(i, A0, A1, A2);
+            }
+        }
+    }
+    st.from = start;
+    if (mode == 2) {
+        st.count = out == SEG_NONE ? 0 : count;
+        st.dc[0] = dc0, st.dc[1] = dc1, st.dc[2] = dc2;
+        st.out_check = out;
+    } else {
+        outs[u].v[mode == 0 ? 0 : wr] = out;
+    }
+    segs[u] = st;
+}
+
+// one lane per segmented file: which file each segment belongs to
+__global__ void __launch_bounds__(64) jpeg_seg_map_kernel(const SegFile *__restrict__ files, uint32_t n_files, uint32_t *__restrict__ seg_file)
+{
+    const uint32_t f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= n_files) return;
+    const SegFile F = files[f];
+    for (uint32_t t = 0; t < F.n_segs; t++) seg_file[F.first_seg + t] = f;
+}
+
+// one lane per segmented file: verify the chain, turn the segments into walk items
+__global__ void __launch_bounds__(64) jpeg_seg_items_kernel(const SegFile *__restrict__ files, uint32_t n_files, const SegState *__restrict__ segs, const SegOut2 *__restrict__ outs,
+                                                            int final_slot, HItem *__restrict__ items)
+{
+    const uint32_t f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= n_files) return;
+    const SegFile F = files[f];
+    bool ok = true;
+    uint32_t running = 0, prev_out = 0;
+    int dc0 = 0, dc1 = 0, dc2 = 0;
+    for (uint32_t t = 0; t < F.n_segs; t++) {
+        const SegState st = segs[F.first_seg + t];
+        const uint32_t out = outs[F.first_seg + t].v[final_slot];
+        const uint32_t seg_first = running;
+        uint32_t cnt = 0;
+        if (st.entry != (t == 0 ? 0u : prev_out) || st.entry == SEG_NONE || out == SEG_NONE || st.out_check != out) ok = false;
+        if (ok) {
+            cnt = st.count < F.total_mcus - running ? st.count : F.total_mcus - running;  // (behind the last MCU a decode sees padding)
+            running += cnt;
+        }
+        HItem it;
+        it.image = F.image, it.scan = 0, it.mcu_first = seg_first, it.mcu_count = cnt;
+        it.stream_off = st.entry == SEG_NONE ? 0 : st.entry >> 3;
+        it.bit_skip = st.entry == SEG_NONE ? 0 : st.entry & 7;
+        it.dc[0] = dc0, it.dc[1] = dc1, it.dc[2] = dc2;
+        items[F.first_item + t] = it;
+        dc0 += st.dc[0], dc1 += st.dc[1], dc2 += st.dc[2];
+        prev_out = out;
+    }
+    if (!ok || running != F.total_mcus) {  // the chain did not settle (or the file is damaged): one lane walks the whole file, as without segments
+        for (uint32_t t = 0; t < F.n_segs; t++) items[F.first_item + t].mcu_count = 0;
+        HItem it;
+        it.image = F.image, it.scan = HITEM_ALL_SCANS, it.mcu_first = 0, it.mcu_count = 0, it.stream_off = 0, it.bit_skip = 0;
+        it.dc[0] = it.dc[1] = it.dc[2] = 0;
+        items[F.first_item] = it;
+    }
+}
+
 }  // namespace
 
 int rph_jpeg_launch_idct(int flavour, uint32_t max_blocks, uint32_t n_planes, hipStream_t stream, const int16_t *d_coef, const uint16_t *d_tables, const JPlane *d_planes,
@@ -528,14 +747,36 @@ int rph_jpeg_launch_color(int flavour, uint32_t max_groups, uint32_t n_images, h
     return RPH_OK;
 }
 
-int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const HItem *d_items, const uint32_t *d_order, uint32_t n_items,
-                         const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status)
+int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const HItem *d_items, const uint32_t *d_order, uint32_t n_ordered,
+                         uint32_t n_items, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status)
 {
     const dim3 grid((n_items + 63) / 64);
     if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
-        hipLaunchKernelGGL(jpeg_huff_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, stream, d_streams, d_images, d_items, d_order, n_items, d_luts, n_luts, d_coef, d_status);
+        hipLaunchKernelGGL(jpeg_huff_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, stream, d_streams, d_images, d_items, d_order, n_ordered, n_items, d_luts, n_luts, d_coef,
+                           d_status);
     else
-        hipLaunchKernelGGL(jpeg_huff_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_items, d_order, n_items, d_luts, n_luts, d_coef, d_status);
+        hipLaunchKernelGGL(jpeg_huff_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_items, d_order, n_ordered, n_items, d_luts, n_luts, d_coef, d_status);
+    RPH_HIP_CHECK(hipGetLastError());
+    return RPH_OK;
+}
+
+int rph_jpeg_launch_segments(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const SegFile *d_files, uint32_t n_files, SegState *d_segs,
+                             uint32_t n_segs, uint32_t seg_bytes, uint32_t *d_bitmap, int rounds, const rphj::DeviceLut *d_luts, HItem *d_items)
+{
+    if (n_files == 0 || n_segs == 0) return RPH_OK;
+    // d_bitmap: n_segs * seg_bytes of marks, then n_segs double-buffered `out` positions, then the segment -> file map
+    SegOut2 *d_outs = reinterpret_cast<SegOut2 *>(reinterpret_cast<uint8_t *>(d_bitmap) + (size_t)n_segs * seg_bytes);
+    uint32_t *d_seg_file = reinterpret_cast<uint32_t *>(d_outs + n_segs);
+    hipLaunchKernelGGL(jpeg_seg_map_kernel, dim3((n_files + 63) / 64), dim3(64), 0, stream, d_files, n_files, d_seg_file);
+    RPH_HIP_CHECK(hipMemsetAsync(d_bitmap, 0, (size_t)n_segs * seg_bytes, stream));
+    RPH_HIP_CHECK(hipMemsetAsync(d_outs, 0xFF, (size_t)n_segs * sizeof(SegOut2), stream));
+    RPH_HIP_CHECK(hipMemsetAsync(d_segs, 0xFF, (size_t)n_segs * sizeof(SegState), stream));
+    const dim3 grid((n_segs + 63) / 64);
+    hipLaunchKernelGGL(jpeg_sync_kernel, grid, dim3(64), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_bitmap, 0, 0, d_luts);
+    for (int r = 1; r <= rounds; r++)
+        hipLaunchKernelGGL(jpeg_sync_kernel, grid, dim3(64), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_bitmap, 1, r, d_luts);
+    hipLaunchKernelGGL(jpeg_sync_kernel, grid, dim3(64), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_bitmap, 2, 0, d_luts);
+    hipLaunchKernelGGL(jpeg_seg_items_kernel, dim3((n_files + 63) / 64), dim3(64), 0, stream, d_files, n_files, d_segs, d_outs, rounds & 1, d_items);
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }

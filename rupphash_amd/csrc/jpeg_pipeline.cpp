@@ -78,6 +78,8 @@ struct Slot {
     Twin meta;              // descriptors (planes | images | tables | HImage | order | DeviceLut)
     Twin res;               // results
     size_t res_images = 0;
+    uint8_t *d_segwork = nullptr;  // device entropy, segmented streams: states | MCU-start bitmaps | out positions
+    size_t segwork_cap = 0;
     void release()
     {
         if (stream) (void)hipStreamSynchronize(stream);
@@ -85,6 +87,7 @@ struct Slot {
         stream_bytes.release();
         meta.release();
         res.release();
+        if (d_segwork) (void)hipFree(d_segwork);
         if (stream) (void)hipStreamDestroy(stream);
         if (done) (void)hipEventDestroy(done);
         *this = Slot();
@@ -550,7 +553,9 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     for (uint32_t g : idx) {
         const rphj::Frame &f = jobs[g].frame;
         const uint64_t mcus = (uint64_t)f.mcus_x * f.mcus_y, intervals = f.restart_interval ? (mcus + f.restart_interval - 1) / f.restart_interval : 1;
-        max_len = std::max(max_len, jobs[g].len / (size_t)std::max<uint64_t>(1, intervals));
+        size_t lane_len = jobs[g].len / (size_t)std::max<uint64_t>(1, intervals);
+        if (!f.restart_interval && ctx->jpeg_seg_bytes && jobs[g].len >= ctx->jpeg_seg_min_bytes) lane_len = ctx->jpeg_seg_bytes;  // (segments: three short passes)
+        max_len = std::max(max_len, lane_len);
     }
     size_t min_chunk = (size_t)16 << 30, parts = 0.65e-6 * (double)max_len > 0.08 ? 2 : 4;
     if (const char *e = getenv("RPH_JPEG_CHUNK_GB")) min_chunk = (size_t)atoi(e) << 30;  // experiments
@@ -670,6 +675,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         // Work items: one per restart interval where a file has them, else one per file; lanes take them longest first.
         std::vector<HItem> items;
         std::vector<uint32_t> item_len;
+        std::vector<SegFile> seg_files;
+        uint32_t n_segs = 0;
         items.reserve(m);
         for (size_t i = first; i < last; i++) {
             Job &j = jobs[idx[i]];
@@ -677,6 +684,20 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             if (j.status != RPH_OK) continue;
             const uint32_t r = (uint32_t)(i - first);
             if (j.marks.empty()) {
+                const rphj::ScanPlan &sp0 = j.plan.scan[0];
+                if (ctx->jpeg_seg_bytes && j.plan.n_scans == 1 && sp0.restart_interval == 0 && sp0.stream_len >= ctx->jpeg_seg_min_bytes && sp0.stream_len < ((uint32_t)1 << 28)) {
+                    // a long stream without restart markers: cut into segments that synchronise on the device (jpeg_device.h)
+                    const rphj::Frame &f = j.frame;
+                    SegFile sf;
+                    sf.image = r;
+                    sf.first_seg = n_segs;
+                    sf.n_segs = (sp0.stream_len + ctx->jpeg_seg_bytes - 1) / ctx->jpeg_seg_bytes;
+                    sf.first_item = 0;  // set below, behind the host's items
+                    sf.total_mcus = sp0.ns == 1 ? f.comp[sp0.ci[0]].real_bw * f.comp[sp0.ci[0]].real_bh : f.mcus_x * f.mcus_y;
+                    n_segs += sf.n_segs;
+                    seg_files.push_back(sf);
+                    continue;
+                }
                 items.push_back(HItem{r, HITEM_ALL_SCANS, 0, 0, 0});
                 item_len.push_back((uint32_t)std::min<size_t>(j.len, 0xFFFFFFFFu));
                 continue;
@@ -695,12 +716,28 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         std::vector<uint32_t> order(items.size());
         for (uint32_t t = 0; t < order.size(); t++) order[t] = t;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return item_len[a] > item_len[b]; });
+        // the segments' items follow the host's: the device writes them, and the lanes take them as they lie (they are short, so they go last)
+        const uint32_t n_ordered = (uint32_t)items.size();
+        uint32_t n_items = n_ordered;
+        for (SegFile &sf : seg_files) {
+            sf.first_item = n_items;
+            n_items += sf.n_segs;
+        }
         const std::vector<rphj::DeviceLut> &luts = store.luts;
         // ---- meta buffer: reconstruction descriptors | HImage | order | tables
         const size_t recon_bytes = m * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128);
-        const size_t off_himg = align_up(recon_bytes, 16), off_items = off_himg + m * sizeof(HImage), off_order = off_items + items.size() * sizeof(HItem),
-                     off_luts = align_up(off_order + order.size() * 4, 16), meta_bytes = off_luts + luts.size() * sizeof(rphj::DeviceLut);
+        // (the items of the segments exist on the device only: d_meta has room for them, the upload stops before them)
+        const size_t off_himg = align_up(recon_bytes, 16), off_order = off_himg + m * sizeof(HImage), off_luts = align_up(off_order + order.size() * 4, 16),
+                     off_segf = align_up(off_luts + luts.size() * sizeof(rphj::DeviceLut), 16), off_items = align_up(off_segf + seg_files.size() * sizeof(SegFile), 16),
+                     upload_bytes = off_items + items.size() * sizeof(HItem), meta_bytes = off_items + (size_t)n_items * sizeof(HItem);
         RPH_TRY(S.meta.reserve(meta_bytes));
+        const size_t segwork = align_up((size_t)n_segs * sizeof(SegState), 16) + (size_t)n_segs * (ctx->jpeg_seg_bytes + 12) + 64;
+        if (n_segs && S.segwork_cap < segwork) {
+            if (S.d_segwork) (void)hipFree(S.d_segwork);
+            S.d_segwork = nullptr, S.segwork_cap = 0;
+            RPH_HIP_CHECK(hipMalloc((void **)&S.d_segwork, segwork + segwork / 4));
+            S.segwork_cap = segwork + segwork / 4;
+        }
         ChunkDesc D;
         std::vector<size_t> subs;
         RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, false, P.recon_coef_bytes[b], S.meta.h, 0, D, subs));
@@ -708,10 +745,11 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         memcpy(S.meta.h + off_items, items.data(), items.size() * sizeof(HItem));
         memcpy(S.meta.h + off_order, order.data(), order.size() * 4);
         if (!luts.empty()) memcpy(S.meta.h + off_luts, luts.data(), luts.size() * sizeof(rphj::DeviceLut));
+        if (n_segs) memcpy(S.meta.h + off_segf, seg_files.data(), seg_files.size() * sizeof(SegFile));
         // ---- device: streams up, zeroed coefficients, the walk, then reconstruction + hashing sub-batch by sub-batch
         const double t_desc = now_ms();
         const bool tr = trace_on();  // RPH_JPEG_TRACE: synchronise after every phase and print where the time goes (stderr)
-        double t_up = 0, t_zero = 0, t_walk = 0, t_rec = 0;
+        double t_up = 0, t_seg = 0, t_zero = 0, t_walk = 0, t_rec = 0;
         auto lap = [&](double &t) {
             if (tr) {
                 (void)hipStreamSynchronize(s);
@@ -720,14 +758,22 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         };
         ResView R(S.res.d, S.res_images);
         RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
-        if (!order.empty()) {
+        if (n_items) {
             RPH_HIP_CHECK(hipMemcpyAsync(S.stream_bytes.d, S.stream_bytes.h, file_bytes + 64, hipMemcpyHostToDevice, s));
-            RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, meta_bytes, hipMemcpyHostToDevice, s));
+            RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, upload_bytes, hipMemcpyHostToDevice, s));
             lap(t_up);
+            if (n_segs) {  // streams without markers: their segments find their entries and become walk items
+                SegState *d_segs = reinterpret_cast<SegState *>(S.d_segwork);
+                uint32_t *d_bitmap = reinterpret_cast<uint32_t *>(S.d_segwork + align_up((size_t)n_segs * sizeof(SegState), 16));
+                RPH_TRY(rph_jpeg_launch_segments(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const SegFile *>(S.meta.d + off_segf),
+                                                 (uint32_t)seg_files.size(), d_segs, n_segs, ctx->jpeg_seg_bytes, d_bitmap, 8,
+                                                 reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), reinterpret_cast<HItem *>(S.meta.d + off_items)));
+            }
+            lap(t_seg);
             RPH_HIP_CHECK(hipMemsetAsync(d_coef, 0, blocks * 128, s));
             lap(t_zero);
             RPH_TRY(rph_jpeg_launch_walk(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const HItem *>(S.meta.d + off_items),
-                                         reinterpret_cast<const uint32_t *>(S.meta.d + off_order), (uint32_t)order.size(),
+                                         reinterpret_cast<const uint32_t *>(S.meta.d + off_order), n_ordered, n_items,
                                          reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, R.status));
             lap(t_walk);
             for (size_t q = 0; q < subs.size(); q++) {
@@ -737,8 +783,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             lap(t_rec);
             if (tr)
                 fprintf(stderr, "[rph_jpeg] chunk of %zu files in %zu lanes (%.1f MB of entropy bytes, %.2f GB of coefficients, %zu tables, %zu sub-batches): prepare %.1f ms, "
-                                "descriptors %.1f ms, upload %.1f ms, zero %.1f ms, walk %.1f ms, reconstruct + hash %.1f ms\n",
-                        m, order.size(), file_bytes / 1e6, blocks * 128 / 1e9, luts.size(), subs.size(), t_prep - t0, t_desc - t_prep, t_up - t_desc, t_zero - t_up, t_walk - t_zero, t_rec - t_walk);
+                                "descriptors %.1f ms, upload %.1f ms, %u segments %.1f ms, zero %.1f ms, walk %.1f ms, reconstruct + hash %.1f ms\n",
+                        m, (size_t)n_items, file_bytes / 1e6, blocks * 128 / 1e9, luts.size(), subs.size(), t_prep - t0, t_desc - t_prep, t_up - t_desc, n_segs, t_seg - t_up, t_zero - t_seg, t_walk - t_zero, t_rec - t_walk);
         }
         RPH_HIP_CHECK(hipEventRecord(S.done, s));
         RPH_JPEG_STAMP("lane %d: chunk %d enqueued", b, k);
@@ -794,7 +840,12 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
     uint64_t lanes = 0;
     for (uint32_t i : dev_idx) {
         const rphj::Frame &f = jobs[i].frame;
-        lanes += f.restart_interval ? ((uint64_t)f.mcus_x * f.mcus_y + f.restart_interval - 1) / f.restart_interval : 1;
+        if (f.restart_interval)
+            lanes += ((uint64_t)f.mcus_x * f.mcus_y + f.restart_interval - 1) / f.restart_interval;
+        else if (ctx->jpeg_seg_bytes && jobs[i].len >= ctx->jpeg_seg_min_bytes)
+            lanes += jobs[i].len / ctx->jpeg_seg_bytes;  // a long stream without markers is cut into segments
+        else
+            lanes += 1;
     }
     if (ctx->jpeg_entropy == 2 && lanes < DEVICE_ENTROPY_MIN_FILES) {
         host_idx.clear();
@@ -896,6 +947,18 @@ int rph_jpeg_coefficients(const uint8_t *data, size_t len, uint32_t *geometry, u
         }
         return RPH_OK;
     });
+}
+
+int rph_jpeg_set_segments(rph_ctx *ctx, uint32_t min_stream_bytes, uint32_t segment_bytes)
+{
+    if (!ctx || (segment_bytes && (segment_bytes < 64 || segment_bytes > 65536 || (segment_bytes & 3)))) {
+        rph_set_error("rph_jpeg_set_segments: invalid argument");
+        return RPH_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lock(ctx->jpeg_mu);
+    ctx->jpeg_seg_min_bytes = min_stream_bytes;
+    ctx->jpeg_seg_bytes = segment_bytes;
+    return RPH_OK;
 }
 
 int rph_jpeg_release(rph_ctx *ctx)

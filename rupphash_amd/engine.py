@@ -134,6 +134,10 @@ class Engine:
                                            C.cast(C.byref(valid), C.c_void_p)), "rph_jpeg_pdq_hash_one")
         return (hash32, q.value, coeffs) if valid.value else None
 
+    def jpeg_set_segments(self, min_stream_bytes=65536, segment_bytes=1024):
+        """device walk of streams without restart markers: cut into segments from min_stream_bytes of entropy data (segment_bytes = 0: never)"""
+        check(self.L.rph_jpeg_set_segments(self.ctx, int(min_stream_bytes), int(segment_bytes)), "rph_jpeg_set_segments")
+
     def jpeg_release(self):
         """give the JPEG path's cached staging / device buffers back"""
         check(self.L.rph_jpeg_release(self.ctx), "rph_jpeg_release")

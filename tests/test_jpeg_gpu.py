@@ -219,6 +219,40 @@ def test_one_file_per_call_from_many_threads(eng, oracle):
             assert np.array_equal(c.view(np.uint32), ref["coeffs"][i].view(np.uint32)), i
 
 
+@pytest.mark.parametrize("seg_bytes", [64, 256, 1024])
+def test_streams_without_markers_cut_into_segments(eng, oracle, seg_bytes):
+    """streams without restart markers walked as segments that synchronise on the device: every sampling layout, gray, tiny and large
+    files, optimised tables, noise (long codes) and flat images (MCUs of a few bits), forced on for every file (min 0) at three segment
+    sizes; the results must be the host decoder's whatever the segmentation"""
+    from PIL import Image
+
+    files = []
+    for k, (w, h, mode, ss) in enumerate([(640, 400, "RGB", 2), (333, 517, "RGB", 1), (200, 120, "RGB", 0), (97, 61, "L", 0), (1280, 854, "RGB", 2), (16, 16, "RGB", 2),
+                                          (8, 8, "L", 0), (500, 40, "RGB", 2)]):
+        kw = dict(quality=[50, 75, 90, 97][k % 4], optimize=bool(k % 3 == 1))
+        if mode == "RGB":
+            kw["subsampling"] = ss
+        files.append(ju.pillow_jpeg(ju.make_image(w, h, mode, seed=90 + k), **kw))
+    rng = np.random.default_rng(3)
+    files.append(ju.pillow_jpeg(Image.fromarray(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)), quality=95, subsampling=0))  # noise: long codes, long MCUs
+    files.append(ju.pillow_jpeg(Image.fromarray(np.full((600, 800, 3), 77, np.uint8)), quality=90, subsampling=2))                 # flat: MCUs of ~30 bits
+    files.append(ju.encode_baseline(np.array(ju.make_image(240, 160, seed=99)), ((1, 2), (1, 1), (1, 1)), 0.5, 0))                  # 4:4:0
+    files.append(ju.encode_baseline(np.array(ju.make_image(240, 160, seed=98)), ((2, 1), (2, 1), (2, 1)), 2.0, 0))                  # chroma at luma resolution
+    files = files * 3
+    eng.jpeg_set_entropy(0)
+    host = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    eng.jpeg_set_entropy(1)
+    eng.jpeg_set_segments(0, seg_bytes)
+    dev = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    eng.jpeg_set_segments(65536, 1024)
+    eng.jpeg_set_entropy(2)
+    assert dev["valid"].all() and not dev["status"].any()
+    assert np.array_equal(dev["hash"], host["hash"]) and np.array_equal(dev["coeffs"].view(np.uint32), host["coeffs"].view(np.uint32))
+    for k in (0, 4, 8, 9):
+        ok, h, _, _ = _oracle_hash(oracle, oracle.jpeg_decode(files[k], 0))
+        assert ok and np.array_equal(dev["hash"][k], h)
+
+
 def test_restart_intervals_get_a_lane_each(eng, oracle):
     """one-scan files with restart markers are walked by one lane per interval; 60 photos with an interval per MCU row are 3 000+
     lanes, so the automatic mode takes the device walk for them; hashes equal the host decoder's and the oracle's"""

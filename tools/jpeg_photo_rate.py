@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--seg", default="", help="comma list of segment sizes (bytes) to try on the files without restart markers; 0 = one lane per file")
     a = ap.parse_args()
     from PIL import Image
 
@@ -53,6 +54,17 @@ def main():
         assert out["valid"].all()
         mb = sum(len(base[k % len(base)]) for k in range(n)) / 1e6
         print(f"{label:50s} n={n:6d}: {n / dt:8.0f} files/s  {mb / dt:7.1f} MB/s of JPEG  {n * 1280 * 854 / dt / 1e9:6.2f} Gpixel/s")
+    for seg in [int(x) for x in a.seg.split(",") if x]:
+        eng.jpeg_set_entropy(1)
+        eng.jpeg_set_segments(65536, seg)
+        for n in (a.n, 2048):
+            files = eng.jpeg_file_list([variants[k % 16] for k in range(n)])
+            eng.jpeg_pdq_hash_batch(files, threads=16)
+            t = time.perf_counter()
+            out = eng.jpeg_pdq_hash_batch(files, threads=16)
+            dt = time.perf_counter() - t
+            assert out["valid"].all()
+            print(f"baseline 4:2:0 q90, segments of {seg:5d} bytes           n={n:6d}: {n / dt:8.0f} files/s")
     eng.close()
 
 
