@@ -134,6 +134,203 @@ __global__ void __launch_bounds__(64) tail_generic_kernel(const float *__restric
                   coeffs ? coeffs + (size_t)img * 256 : nullptr, dihedral ? dihedral + (size_t)img * 256 : nullptr);
 }
 
+
+// ---- the same passes with the row lines staged through LDS (the default; the kernels above stay as the plain baseline,
+// rph_pdq_set_kernel(ctx, 0)).  A lane that walks its own row reads one cache line per lane and step; here a wave (64 rows) loads
+// 64-column tiles with lane = column (whole lines), walks them out of LDS with lane = row, and stores its outputs with lane = column again.
+// The arithmetic per line is the reference's, step for step (pdqhash.rs:341-396), written as one loop over t = index of the incoming sample:
+//   t < len: sum += in[t] (and cur += 1 while the window fills: t < win);  t >= win: sum -= in[t - win] (and cur -= 1 once t >= len);
+//   t >= half - 1: out[t - (half - 1)] = sum / cur.
+// The second row pass only feeds decimate_float (pdqhash.rs:428-443), which keeps 64 columns: it emits those and nothing else, so the second
+// column pass and the tail work on [h][64] values per image.
+constexpr int BT_HIST = 8;                  // columns of the previous tile kept in front of the current one (window <= 8)
+constexpr int BT_PITCH = BT_HIST + 65;      // floats per tile row (odd: lane = row accesses are conflict-free)
+
+struct BoxGeo {
+    uint32_t win, half, lead;  // window, (win + 2) / 2, half - 1
+};
+__device__ __forceinline__ BoxGeo box_geo(uint32_t len, uint32_t win)
+{
+    const uint32_t maxlen = len > 1 ? len : 1;
+    win = win < 1 ? 1 : (win > maxlen ? maxlen : win);
+    BoxGeo g;
+    g.win = win;
+    g.half = (win + 2) / 2;
+    g.lead = g.half - 1;
+    return g;
+}
+
+// SRC_U8: the source is the caller's pixels (1, 3 or 4 channels: to_luma601 on the way in), else an f32 plane [n][h][w].
+// SAMPLED: only the 64 columns decimate_float keeps are written, to out[line][64]; else the whole line, out[line][w].
+// One tile in LDS, used in place: the sample that enters at step s sits in slot s; the output of step s (column c0 + s - lead) goes to slot
+// s - win, whose sample has just been subtracted for the last time.  The next tile is fetched into registers while this one is walked.
+template <bool SRC_U8, bool SAMPLED>
+__global__ void __launch_bounds__(64) box_rows_tiled_kernel(const void *__restrict__ src_, uint32_t n, uint32_t h, uint32_t w, uint32_t channels, size_t row_stride,
+                                                            size_t image_stride, uint32_t win_, float *__restrict__ out)
+{
+    __shared__ float t_in[64 * BT_PITCH];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t lines = (uint64_t)n * h, line0 = (uint64_t)blockIdx.x * 64;
+    const uint32_t n_rows = (uint32_t)min((uint64_t)64, lines - line0);
+    const BoxGeo g = box_geo(w, win_);
+    // source offset of this lane's own line (rows past the end repeat the last line: loaded, never stored)
+    const uint64_t my_line = min(line0 + lane, lines - 1);
+    size_t my_off;
+    if (SRC_U8) {
+        const uint32_t img = (uint32_t)(my_line / h), y = (uint32_t)(my_line - (uint64_t)img * h);
+        my_off = (size_t)img * image_stride + (size_t)y * row_stride;
+    } else {
+        my_off = (size_t)my_line * w;
+    }
+    const uint32_t off_lo = (uint32_t)my_off, off_hi = (uint32_t)(my_off >> 32);
+    float pre[64];  // the tile being fetched: row rr at column c0 + lane
+    auto fetch = [&](uint32_t c0) {
+        const uint32_t c = min(c0 + lane, w - 1);  // (columns past the end repeat the last one: never used by a step with t < w)
+#pragma unroll
+        for (int rr = 0; rr < 64; rr++) {
+            const size_t off = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)off_lo, rr) | (size_t)(uint32_t)__builtin_amdgcn_readlane((int)off_hi, rr) << 32;
+            if (SRC_U8) {
+                const uint8_t *p = static_cast<const uint8_t *>(src_) + off + (size_t)c * channels;
+                pre[rr] = channels == 1 ? (float)p[0] : (float)((299u * p[0] + 587u * p[1] + 114u * p[2] + 500u) / 1000u);
+            } else {
+                pre[rr] = static_cast<const float *>(src_)[off + c];
+            }
+        }
+    };
+    float sum = 0.0f, cur = 0.0f;
+    uint32_t next_sample = 0;  // SAMPLED: column of sample j = ((2 j + 1) w) / 128
+    const uint32_t total = w + g.lead;
+    float *mine = t_in + lane * BT_PITCH + BT_HIST;
+    fetch(0);
+    for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+        if (c0 < w) {
+#pragma unroll
+            for (int rr = 0; rr < 64; rr++) t_in[rr * BT_PITCH + BT_HIST + lane] = pre[rr];
+        }
+        __syncthreads();
+        if (c0 + 64 < w) fetch(c0 + 64);
+        // ---- walk: lane = row
+        const uint32_t steps = min(64u, total - c0);
+        if (c0 >= g.win && c0 + 64 <= w) {  // every step adds, subtracts and emits, over a full window
+            const int d = (int)g.win;
+            for (int s = 0; s < 64; s += 8) {
+                float r[8], l[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    r[k] = mine[s + k];
+                    l[k] = mine[s + k - d];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    sum = sum + r[k];
+                    sum = sum - l[k];
+                    l[k] = sum / cur;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) mine[s + k - d] = l[k];
+            }
+        } else {
+            for (uint32_t s = 0; s < steps; s++) {
+                const uint32_t t = c0 + s;
+                if (t < w) {
+                    sum = sum + mine[s];
+                    if (t < g.win) cur = cur + 1.0f;
+                }
+                if (t >= g.win) {
+                    sum = sum - mine[(int)s - (int)g.win];
+                    if (t >= w) cur = cur - 1.0f;
+                }
+                if (t >= g.lead) mine[(int)s - (int)g.win] = sum / cur;
+            }
+        }
+        __syncthreads();
+        // ---- out, lane = column again
+        if (!SAMPLED) {
+            const int64_t oc = (int64_t)c0 + lane - g.lead;  // the output of step s = lane
+            const bool ok = oc >= 0 && oc < (int64_t)w && lane < steps;
+            const float *from = t_in + BT_HIST + (int)lane - (int)g.win;
+            float *to = out + (size_t)line0 * w + (ok ? (size_t)oc : 0);
+#pragma unroll 16
+            for (uint32_t rr = 0; rr < n_rows; rr++)
+                if (ok) to[(size_t)rr * w] = from[rr * BT_PITCH];
+        } else {
+            // samples whose step lies in this tile: j0 .. j0 + nj - 1, lane = sample
+            const uint32_t j0 = next_sample;
+            while (next_sample < 64 && ((2u * next_sample + 1u) * w) / 128u + g.lead < c0 + steps) next_sample++;
+            const uint32_t nj = next_sample - j0;
+            if (nj) {
+                const uint32_t j = j0 + min(lane, nj - 1);
+                const int slot = (int)(((2u * j + 1u) * w) / 128u + g.lead - c0) - (int)g.win;
+                const float *from = t_in + BT_HIST + slot;
+                float *to = out + (size_t)line0 * 64 + j;
+#pragma unroll 16
+                for (uint32_t rr = 0; rr < n_rows; rr++)
+                    if (lane < nj) to[(size_t)rr * 64] = from[rr * BT_PITCH];
+            }
+        }
+        __syncthreads();
+        // the last BT_HIST slots (the samples still to be subtracted among them) move in front of the next tile
+        float keep[BT_HIST];
+#pragma unroll
+        for (int k = 0; k < BT_HIST; k++) keep[k] = mine[64 - BT_HIST + k];
+#pragma unroll
+        for (int k = 0; k < BT_HIST; k++) mine[k - BT_HIST] = keep[k];
+        __syncthreads();
+    }
+}
+
+// second column pass on the 64 kept columns + decimate_float's rows + tail; one wave per image, lane = kept column.
+// The column is walked 64 rows at a time out of LDS (the loads of a chunk are independent of the running sum and go out together).
+__global__ void __launch_bounds__(64) tail_sampled_kernel(const float *__restrict__ kept, uint32_t n, uint32_t h, uint32_t win_, uint8_t *hash, float *quality,
+                                                          float *coeffs, uint8_t *dihedral)
+{
+    __shared__ float lds[rph::TAIL_LDS_FLOATS];
+    __shared__ float t_k[(BT_HIST + 64) * 64];  // rows r0 - 8 .. r0 + 63 of this image's kept columns
+    __shared__ float t_b[64 * 64];              // the 64 kept rows
+    const uint32_t img = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float *p = kept + (size_t)img * h * 64 + lane;
+    const BoxGeo g = box_geo(h, win_);
+    float sum = 0.0f, cur = 0.0f;
+    uint32_t next_sample = 0, next_row = h / 128u;  // row of sample i = ((2 i + 1) h) / 128
+    const uint32_t total = h + g.lead;
+    for (uint32_t r0 = 0; r0 < total; r0 += 64) {
+        if (r0 < h) {
+            const uint32_t rows = min(64u, h - r0);
+            for (uint32_t rr = 0; rr < rows; rr++) t_k[(BT_HIST + rr) * 64 + lane] = p[(size_t)(r0 + rr) * 64];
+        }
+        const uint32_t steps = min(64u, total - r0);
+        const float *mine = t_k + BT_HIST * 64 + lane;
+#pragma unroll 4
+        for (uint32_t s = 0; s < steps; s++) {
+            const uint32_t t = r0 + s;
+            if (t < h) {
+                sum = sum + mine[s * 64];
+                if (t < g.win) cur = cur + 1.0f;
+            }
+            if (t >= g.win) {
+                sum = sum - mine[((int)s - (int)g.win) * 64];
+                if (t >= h) cur = cur - 1.0f;
+            }
+            if (t >= g.lead) {
+                const float o = sum / cur;
+                while (next_sample < 64 && next_row == t - g.lead) {  // (heights below 64 keep a row more than once)
+                    t_b[next_sample * 64 + lane] = o;
+                    next_sample++;
+                    next_row = ((2u * next_sample + 1u) * h) / 128u;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BT_HIST; k++) t_k[k * 64 + lane] = t_k[(64 + k) * 64 + lane];
+    }
+    float b[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) b[i] = t_b[i * 64 + lane];
+    rph::pdq_tail(b, lds, lane, hash ? hash + (size_t)img * 32 : nullptr, quality ? quality + img : nullptr,
+                  coeffs ? coeffs + (size_t)img * 256 : nullptr, dihedral ? dihedral + (size_t)img * 256 : nullptr);
+}
+
 // PdqFeatures::to_hash / generate_dihedral_hashes for stored coefficients; one wave per image
 __global__ void __launch_bounds__(64) from_coeffs_kernel(const float *__restrict__ coeffs, uint32_t n, uint8_t *hash,
                                                          uint8_t *dihedral)
@@ -211,7 +408,7 @@ int rph_launch_pdq_generic(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
 {
     if (n == 0) return RPH_OK;
     if (d_valid) RPH_HIP_CHECK(hipMemsetAsync(d_valid, 1, n, stream));
-    const size_t plane_bytes = (size_t)w * h * sizeof(float);
+    const size_t plane_bytes = (size_t)(w > 64 ? w : 64) * h * sizeof(float);  // (a plane also holds the 64 kept columns of every row)
     // two planes per image in flight; cap the scratch at 512 MiB
     uint32_t chunk = (uint32_t)((size_t)(256u << 20) / plane_bytes);
     if (chunk < 1) chunk = 1;
@@ -230,11 +427,24 @@ int rph_launch_pdq_generic(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
     // user's kernels if they went to another stream
     if (!ctx->scratch_done) RPH_HIP_CHECK(hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));
     if (ctx->scratch_used && ctx->scratch_stream != stream) RPH_HIP_CHECK(hipStreamWaitEvent(stream, ctx->scratch_done, 0));
-    float *a = ctx->scratch, *b = ctx->scratch + (size_t)chunk * w * h;
+    float *a = ctx->scratch, *b = ctx->scratch + (size_t)chunk * (plane_bytes / sizeof(float));
     const uint32_t win_rows = (w + 63) / 64;  // window along rows = ceil(cols / 64)   pdqhash.rs:246
     const uint32_t win_cols = (h + 63) / 64;  // window along cols = ceil(rows / 64)   pdqhash.rs:247
     for (uint32_t first = 0; first < n; first += chunk) {
         const uint32_t m = (n - first) < chunk ? (n - first) : chunk;
+        if (ctx->pdq_kernel != 0 && win_rows <= (uint32_t)BT_HIST && win_cols <= (uint32_t)BT_HIST) {  // rows through LDS tiles, the second half of the filter on the 64 kept columns only
+            const unsigned row_blocks = (unsigned)(((uint64_t)m * h + 63) / 64);
+            hipLaunchKernelGGL((box_rows_tiled_kernel<true, false>), dim3(row_blocks), dim3(64), 0, stream, (const void *)(d_px + (size_t)first * image_stride), m, h, w,
+                               channels, row_stride, image_stride, win_rows, a);
+            hipLaunchKernelGGL(box_cols_kernel, dim3((unsigned)(((uint64_t)m * w + 63) / 64)), dim3(64), 0, stream, a, b, m, h, w, win_cols);
+            float *kept = a;  // [m][h][64]; plane a has been consumed by the column pass
+            hipLaunchKernelGGL((box_rows_tiled_kernel<false, true>), dim3(row_blocks), dim3(64), 0, stream, (const void *)b, m, h, w, 1u, (size_t)0, (size_t)0, win_rows, kept);
+            hipLaunchKernelGGL(tail_sampled_kernel, dim3(m), dim3(64), 0, stream, kept, m, h, win_cols, d_hash ? d_hash + (size_t)first * 32 : nullptr,
+                               d_quality ? d_quality + first : nullptr, d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr,
+                               d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr);
+            RPH_HIP_CHECK(hipGetLastError());
+            continue;
+        }
         const uint64_t total = (uint64_t)m * w * h;
         const uint64_t want = (total + 255) / 256;
         hipLaunchKernelGGL(luma_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, stream,

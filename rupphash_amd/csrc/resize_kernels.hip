@@ -135,6 +135,70 @@ __global__ void __launch_bounds__(256) resize_v_kernel(const uint8_t *__restrict
 
 unsigned grid_for(uint64_t total) { return (unsigned)std::min<uint64_t>((total + 255) / 256, 65536); }
 
+// ---- both passes in one kernel.  A workgroup owns one image x 64 output columns x `th` output rows: every input row those output rows
+// need is convolved horizontally into a u8 tile in LDS (the u8 rounding of the two-pass form is kept: it is part of the algorithm), then the
+// tile is convolved vertically.  Luma is formed on the way in (to_luma601, pdqhash.rs:268-284), so an Rgb8 source is read once and neither the
+// full-size luma plane nor the half-resized plane exists in HBM.  No 64-bit division per pixel: the grid is (column tile, row tile, image).
+template <int CH>
+__device__ __forceinline__ int32_t luma_at(const uint8_t *p)
+{
+    if (CH == 1) return p[0];
+    return (int32_t)((299u * p[0] + 587u * p[1] + 114u * p[2] + 500u) / 1000u);
+}
+
+constexpr int RZ_TW = 64;      // output columns per workgroup
+constexpr int RZ_KREG = 8;     // window lengths up to this keep their coefficients in registers
+
+template <int CH>
+__global__ void __launch_bounds__(256) resize_fused_kernel(const uint8_t *__restrict__ px, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride,
+                                                           uint32_t nw, uint32_t nh, DevAxis ax, DevAxis ay, uint32_t th, uint32_t tile_rows,
+                                                           uint8_t *__restrict__ dst)
+{
+    extern __shared__ uint8_t rz_tile[];  // [tile_rows][RZ_TW]
+    const uint32_t lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const uint32_t img = blockIdx.z, r0 = blockIdx.y * th, r1 = min(r0 + th, nh), o = blockIdx.x * RZ_TW + lane;
+    const uint32_t in0 = ay.start[r0];
+    uint32_t in1 = ay.start[r1 - 1] + ay.size[r1 - 1];
+    in1 = min(min(in1, h), in0 + tile_rows);  // (the host sized tile_rows as the maximum over the row tiles: the clamp never bites)
+    if (o < nw) {
+        const uint32_t xs = ax.start[o], xn = ax.size[o];
+        const int16_t *k = ax.coef + (size_t)o * ax.window;
+        const uint8_t *base = px + (size_t)img * image_stride + (size_t)xs * CH;
+        const int32_t half = 1 << (ax.precision - 1);
+        if (xn <= (uint32_t)RZ_KREG) {
+            int32_t kk[RZ_KREG];
+#pragma unroll
+            for (int i = 0; i < RZ_KREG; i++) kk[i] = (uint32_t)i < xn ? (int32_t)k[i] : 0;
+            for (uint32_t y = in0 + sub; y < in1; y += 4) {
+                const uint8_t *row = base + (size_t)y * row_stride;
+                int32_t ss = half;
+#pragma unroll
+                for (int i = 0; i < RZ_KREG; i++)
+                    if ((uint32_t)i < xn) ss += luma_at<CH>(row + i * CH) * kk[i];
+                rz_tile[(y - in0) * RZ_TW + lane] = clip8(ss, ax.precision);
+            }
+        } else {
+            for (uint32_t y = in0 + sub; y < in1; y += 4) {
+                const uint8_t *row = base + (size_t)y * row_stride;
+                int32_t ss = half;
+                for (uint32_t i = 0; i < xn; i++) ss += luma_at<CH>(row + (size_t)i * CH) * (int32_t)k[i];
+                rz_tile[(y - in0) * RZ_TW + lane] = clip8(ss, ax.precision);
+            }
+        }
+    }
+    __syncthreads();
+    if (o < nw) {
+        const int32_t half = 1 << (ay.precision - 1);
+        for (uint32_t r = r0 + sub; r < r1; r += 4) {
+            const uint32_t ys = ay.start[r] - in0, yn = ay.size[r];
+            const int16_t *k = ay.coef + (size_t)r * ay.window;
+            int32_t ss = half;
+            for (uint32_t i = 0; i < yn && ys + i < tile_rows; i++) ss += (int32_t)rz_tile[(ys + i) * RZ_TW + lane] * (int32_t)k[i];
+            dst[((size_t)img * nh + r) * nw + o] = clip8(ss, ay.precision);
+        }
+    }
+}
+
 }  // namespace
 
 // Device copies of the two coefficient tables of a source geometry, built once and kept in the context (a scan meets few
@@ -143,13 +207,14 @@ namespace {
 struct DevAxisOwner {
     DevAxis ax{};
     void *start = nullptr, *size = nullptr, *coef = nullptr;
+    std::vector<uint32_t> h_start, h_size;  // host copies: the fused kernel's tile height is chosen from them
 };
 struct AxisCache {
     std::map<std::pair<uint32_t, uint32_t>, DevAxisOwner> axes;  // (in_size, out_size) -> tables
 };
 constexpr size_t kAxisCacheMax = 256;
 
-int device_axis(rph_ctx *ctx, uint32_t in_size, uint32_t out_size, DevAxis &out)
+int device_axis(rph_ctx *ctx, uint32_t in_size, uint32_t out_size, DevAxis &out, const DevAxisOwner **owner = nullptr)
 {
     if (!ctx->axis_cache) ctx->axis_cache = new AxisCache();
     AxisCache &c = *static_cast<AxisCache *>(ctx->axis_cache);
@@ -173,9 +238,12 @@ int device_axis(rph_ctx *ctx, uint32_t in_size, uint32_t out_size, DevAxis &out)
         RPH_HIP_CHECK(hipMemcpy(o.size, a.size.data(), a.size.size() * 4, hipMemcpyHostToDevice));
         RPH_HIP_CHECK(hipMemcpy(o.coef, a.coef.data(), a.coef.size() * 2, hipMemcpyHostToDevice));
         o.ax = DevAxis{(const uint32_t *)o.start, (const uint32_t *)o.size, (const int16_t *)o.coef, a.window, a.precision};
-        it = c.axes.emplace(std::make_pair(in_size, out_size), o).first;
+        o.h_start = a.start;
+        o.h_size = a.size;
+        it = c.axes.emplace(std::make_pair(in_size, out_size), std::move(o)).first;
     }
     out = it->second.ax;
+    if (owner) *owner = &it->second;
     return RPH_OK;
 }
 }  // namespace
@@ -207,12 +275,26 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
     uint32_t nw, nh;
     rph_pdq_target_dimensions(w, h, RPH_PDQ_MAX_DIM, &nw, &nh);  // pdqhash.rs:183
     DevAxis dx, dy;
+    const DevAxisOwner *oy = nullptr;
     int rc;
-    if ((rc = device_axis(ctx, w, nw, dx)) != RPH_OK || (rc = device_axis(ctx, h, nh, dy)) != RPH_OK) return rc;
+    if ((rc = device_axis(ctx, w, nw, dx)) != RPH_OK || (rc = device_axis(ctx, h, nh, dy, &oy)) != RPH_OK) return rc;
 
-    const size_t full = (size_t)w * h, tmp = (size_t)nw * h, small = (size_t)nw * nh;
-    uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)256 << 20) / full);
-    chunk = std::min(chunk, n);
+    // the fused kernel: rows of output per workgroup such that the input rows they need fit a 32 KB tile
+    uint32_t th = 16, tile_rows = 0;
+    const bool may_fuse = (channels == 1 || channels == 3 || channels == 4) && ctx->pdq_kernel != 0;  // (rph_pdq_set_kernel(ctx, 0): the plain two-pass kernels, the baseline the tests compare with)
+    for (; may_fuse; th /= 2) {
+        tile_rows = 0;
+        for (uint32_t r0 = 0; r0 < nh; r0 += th) {
+            const uint32_t r1 = std::min(r0 + th, nh);
+            tile_rows = std::max(tile_rows, oy->h_start[r1 - 1] + oy->h_size[r1 - 1] - oy->h_start[r0]);
+        }
+        if ((size_t)tile_rows * RZ_TW <= 32768 || th == 1) break;
+    }
+    const bool fused = may_fuse && (size_t)tile_rows * RZ_TW <= 32768 && (nh + th - 1) / th <= 65535;
+
+    const size_t full = fused ? 0 : (size_t)w * h, tmp = fused ? 0 : (size_t)nw * h, small = (size_t)nw * nh;
+    uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)256 << 20) / (fused ? small * 5 : full));  // (small * 5: the hasher's u8 + f32 planes)
+    chunk = std::min(std::min(chunk, n), 65535u);
     const size_t need = (full + tmp + small) * chunk;
     if (ctx->rz_bytes < need) {
         RPH_HIP_CHECK(hipDeviceSynchronize());  // kernels of any stream may still be using the old planes
@@ -228,10 +310,22 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
     uint8_t *p_luma = ctx->rz_scratch, *p_tmp = p_luma + full * chunk, *p_small = p_tmp + tmp * chunk;
     for (uint32_t first = 0; first < n; first += chunk) {
         const uint32_t m = std::min(chunk, n - first);
+        if (fused) {
+            const dim3 grid((nw + RZ_TW - 1) / RZ_TW, (nh + th - 1) / th, m);
+            const uint8_t *src = d_px + (size_t)first * image_stride;
+            const size_t lds = (size_t)tile_rows * RZ_TW;
+            if (channels == 1)
+                hipLaunchKernelGGL(resize_fused_kernel<1>, grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, p_small);
+            else if (channels == 3)
+                hipLaunchKernelGGL(resize_fused_kernel<3>, grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, p_small);
+            else
+                hipLaunchKernelGGL(resize_fused_kernel<4>, grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, p_small);
+        } else {
         hipLaunchKernelGGL(luma_u8_kernel, dim3(grid_for((uint64_t)m * full)), dim3(256), 0, stream, d_px + (size_t)first * image_stride, m, w,
                            h, channels, row_stride, image_stride, p_luma);
         hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for((uint64_t)m * h * nw)), dim3(256), 0, stream, (const uint8_t *)p_luma, p_tmp, m, w, h, nw, dx);
         hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((uint64_t)m * nh * nw)), dim3(256), 0, stream, (const uint8_t *)p_tmp, p_small, m, h, nw, nh, dy);
+        }
         RPH_HIP_CHECK(hipGetLastError());
         // generate_pdq_from_luma on the thumbnail (no second size check in the reference: a 4000x5 input is hashed from 512x1).
         // It records scratch_done on `stream` when it is through, which also covers the planes above.

@@ -59,8 +59,11 @@ GEOMS = [(512, 512, 3), (5, 5, 3), (64, 64, 1), (100, 37, 3), (512, 300, 4), (33
          (129, 65, 3)]
 
 
+@pytest.mark.parametrize("which", [0, 4])
 @pytest.mark.parametrize("w,h,ch", GEOMS)
-def test_pdq_generic_kernel_matches_oracle(eng, oracle, w, h, ch):
+def test_pdq_generic_kernel_matches_oracle(eng, oracle, w, h, ch, which):
+    """which = 0: the plain multi-pass kernels (one thread per line); 4: the default (512x512 fused; elsewhere rows through LDS tiles, the second
+    half of the filter on the 64 kept columns only)"""
     rng = np.random.default_rng(w * 1000 + h + ch)
     n = 3
     if ch == 1:
@@ -69,7 +72,7 @@ def test_pdq_generic_kernel_matches_oracle(eng, oracle, w, h, ch):
         imgs = rng.integers(0, 256, (n, h, w, ch), dtype=np.uint8)
         # smooth structure so the hash is not pure noise: add a gradient to image 0
         imgs[0, ..., 0] = (np.arange(w)[None, :] * 255 // max(w - 1, 1)).astype(np.uint8)
-    eng.set_pdq_kernel(0)
+    eng.set_pdq_kernel(which)
     out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
     eng.set_pdq_kernel(4)
     for k in range(n):
@@ -118,8 +121,9 @@ RESIZED = [(780, 768, 3), (1280, 854, 3), (513, 512, 3), (512, 513, 1), (4000, 5
            (2048, 1536, 3)]
 
 
+@pytest.mark.parametrize("which", [0, 4])
 @pytest.mark.parametrize("w,h,ch", RESIZED)
-def test_pdq_with_predownsample_matches_oracle(eng, oracle, w, h, ch):
+def test_pdq_with_predownsample_matches_oracle(eng, oracle, w, h, ch, which):
     """pdqhash.rs:181-220: sides > 512 px go through luma -> box-convolution thumbnail -> PDQ.  GPU == oracle bit for bit
     (the resize itself is a restatement of third-party code: parity unpinned against the Rust binary)."""
     rng = np.random.default_rng(w * 7 + h)
@@ -133,7 +137,9 @@ def test_pdq_with_predownsample_matches_oracle(eng, oracle, w, h, ch):
     else:
         imgs[0, ..., 0] = grad
         imgs[0, ..., 1] = grad[::-1]
+    eng.set_pdq_kernel(which)  # 0: luma plane + two resize kernels + plain hasher; 4: both resize passes in one kernel, tiled hasher
     out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
+    eng.set_pdq_kernel(4)
     for k in range(n):
         rc, coeffs, q = oracle.pdq_features(imgs[k])
         assert rc == 0 and out["valid"][k] == 1
