@@ -160,11 +160,12 @@ __device__ __forceinline__ BoxGeo box_geo(uint32_t len, uint32_t win)
     return g;
 }
 
-// SRC_U8: the source is the caller's pixels (1, 3 or 4 channels: to_luma601 on the way in), else an f32 plane [n][h][w].
+// SRC: 0 = an f32 plane [n][h][w]; 1 = the caller's Luma8 pixels; 3 = the caller's Rgb8 / Rgba8 pixels (to_luma601 on the way in).  (A template
+// parameter and not a branch on `channels`: with the branch every load of the prefetch waited for the one before.)
 // SAMPLED: only the 64 columns decimate_float keeps are written, to out[line][64]; else the whole line, out[line][w].
 // One tile in LDS, used in place: the sample that enters at step s sits in slot s; the output of step s (column c0 + s - lead) goes to slot
 // s - win, whose sample has just been subtracted for the last time.  The next tile is fetched into registers while this one is walked.
-template <bool SRC_U8, bool SAMPLED>
+template <int SRC, bool SAMPLED>
 __global__ void __launch_bounds__(64) box_rows_tiled_kernel(const void *__restrict__ src_, uint32_t n, uint32_t h, uint32_t w, uint32_t channels, size_t row_stride,
                                                             size_t image_stride, uint32_t win_, float *__restrict__ out)
 {
@@ -175,6 +176,7 @@ __global__ void __launch_bounds__(64) box_rows_tiled_kernel(const void *__restri
     const BoxGeo g = box_geo(w, win_);
     // source offset of this lane's own line (rows past the end repeat the last line: loaded, never stored)
     const uint64_t my_line = min(line0 + lane, lines - 1);
+    constexpr bool SRC_U8 = SRC != 0;
     size_t my_off;
     if (SRC_U8) {
         const uint32_t img = (uint32_t)(my_line / h), y = (uint32_t)(my_line - (uint64_t)img * h);
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(64) box_rows_tiled_kernel(const void *__restri
             const size_t off = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)off_lo, rr) | (size_t)(uint32_t)__builtin_amdgcn_readlane((int)off_hi, rr) << 32;
             if (SRC_U8) {
                 const uint8_t *p = static_cast<const uint8_t *>(src_) + off + (size_t)c * channels;
-                pre[rr] = channels == 1 ? (float)p[0] : (float)((299u * p[0] + 587u * p[1] + 114u * p[2] + 500u) / 1000u);
+                pre[rr] = SRC == 1 ? (float)p[0] : (float)((299u * p[0] + 587u * p[1] + 114u * p[2] + 500u) / 1000u);
             } else {
                 pre[rr] = static_cast<const float *>(src_)[off + c];
             }
@@ -201,6 +203,18 @@ __global__ void __launch_bounds__(64) box_rows_tiled_kernel(const void *__restri
     uint32_t next_sample = 0;  // SAMPLED: column of sample j = ((2 j + 1) w) / 128
     const uint32_t total = w + g.lead;
     float *mine = t_in + lane * BT_PITCH + BT_HIST;
+    // Outputs leave one tile late: they are read out of LDS into registers after the walk and stored while the next tile is walked, so that
+    // nothing waits for a store (loads and stores share one counter: a wait for the prefetched tile is a wait for every store before it).
+    float ost[64];
+    float *ost_to = out;
+    bool ost_ok = false;
+    auto flush = [&]() {
+        if (ost_ok) {
+#pragma unroll
+            for (int rr = 0; rr < 64; rr++)
+                if ((uint32_t)rr < n_rows) ost_to[(size_t)rr * (SAMPLED ? 64 : w)] = ost[rr];
+        }
+    };
     fetch(0);
     for (uint32_t c0 = 0; c0 < total; c0 += 64) {
         if (c0 < w) {
@@ -208,6 +222,7 @@ __global__ void __launch_bounds__(64) box_rows_tiled_kernel(const void *__restri
             for (int rr = 0; rr < 64; rr++) t_in[rr * BT_PITCH + BT_HIST + lane] = pre[rr];
         }
         __syncthreads();
+        flush();
         if (c0 + 64 < w) fetch(c0 + 64);
         // ---- walk: lane = row
         const uint32_t steps = min(64u, total - c0);
@@ -244,28 +259,27 @@ __global__ void __launch_bounds__(64) box_rows_tiled_kernel(const void *__restri
             }
         }
         __syncthreads();
-        // ---- out, lane = column again
+        // ---- outputs into registers, lane = column again
         if (!SAMPLED) {
             const int64_t oc = (int64_t)c0 + lane - g.lead;  // the output of step s = lane
-            const bool ok = oc >= 0 && oc < (int64_t)w && lane < steps;
+            ost_ok = oc >= 0 && oc < (int64_t)w && lane < steps;
+            ost_to = out + (size_t)line0 * w + (ost_ok ? (size_t)oc : 0);
             const float *from = t_in + BT_HIST + (int)lane - (int)g.win;
-            float *to = out + (size_t)line0 * w + (ok ? (size_t)oc : 0);
-#pragma unroll 16
-            for (uint32_t rr = 0; rr < n_rows; rr++)
-                if (ok) to[(size_t)rr * w] = from[rr * BT_PITCH];
+#pragma unroll
+            for (int rr = 0; rr < 64; rr++) ost[rr] = from[rr * BT_PITCH];
         } else {
             // samples whose step lies in this tile: j0 .. j0 + nj - 1, lane = sample
             const uint32_t j0 = next_sample;
             while (next_sample < 64 && ((2u * next_sample + 1u) * w) / 128u + g.lead < c0 + steps) next_sample++;
             const uint32_t nj = next_sample - j0;
+            ost_ok = lane < nj;
             if (nj) {
                 const uint32_t j = j0 + min(lane, nj - 1);
                 const int slot = (int)(((2u * j + 1u) * w) / 128u + g.lead - c0) - (int)g.win;
                 const float *from = t_in + BT_HIST + slot;
-                float *to = out + (size_t)line0 * 64 + j;
-#pragma unroll 16
-                for (uint32_t rr = 0; rr < n_rows; rr++)
-                    if (lane < nj) to[(size_t)rr * 64] = from[rr * BT_PITCH];
+                ost_to = out + (size_t)line0 * 64 + j;
+#pragma unroll
+                for (int rr = 0; rr < 64; rr++) ost[rr] = from[rr * BT_PITCH];
             }
         }
         __syncthreads();
@@ -277,6 +291,7 @@ __global__ void __launch_bounds__(64) box_rows_tiled_kernel(const void *__restri
         for (int k = 0; k < BT_HIST; k++) mine[k - BT_HIST] = keep[k];
         __syncthreads();
     }
+    flush();
 }
 
 // second column pass on the 64 kept columns + decimate_float's rows + tail; one wave per image, lane = kept column.
@@ -409,8 +424,8 @@ int rph_launch_pdq_generic(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
     if (n == 0) return RPH_OK;
     if (d_valid) RPH_HIP_CHECK(hipMemsetAsync(d_valid, 1, n, stream));
     const size_t plane_bytes = (size_t)(w > 64 ? w : 64) * h * sizeof(float);  // (a plane also holds the 64 kept columns of every row)
-    // two planes per image in flight; cap the scratch at 512 MiB
-    uint32_t chunk = (uint32_t)((size_t)(256u << 20) / plane_bytes);
+    // two planes per image in flight; the scratch is capped at 2 GiB
+    uint32_t chunk = (uint32_t)(((size_t)1 << 30) / plane_bytes);  // up to 1 GiB per plane: short launches leave the chip half empty (one wave per image in the tail)
     if (chunk < 1) chunk = 1;
     if (chunk > n) chunk = n;
     const size_t need = 2 * plane_bytes * chunk;
@@ -434,11 +449,15 @@ int rph_launch_pdq_generic(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
         const uint32_t m = (n - first) < chunk ? (n - first) : chunk;
         if (ctx->pdq_kernel != 0 && win_rows <= (uint32_t)BT_HIST && win_cols <= (uint32_t)BT_HIST) {  // rows through LDS tiles, the second half of the filter on the 64 kept columns only
             const unsigned row_blocks = (unsigned)(((uint64_t)m * h + 63) / 64);
-            hipLaunchKernelGGL((box_rows_tiled_kernel<true, false>), dim3(row_blocks), dim3(64), 0, stream, (const void *)(d_px + (size_t)first * image_stride), m, h, w,
-                               channels, row_stride, image_stride, win_rows, a);
+            if (channels == 1)
+                hipLaunchKernelGGL((box_rows_tiled_kernel<1, false>), dim3(row_blocks), dim3(64), 0, stream, (const void *)(d_px + (size_t)first * image_stride), m, h, w,
+                                   channels, row_stride, image_stride, win_rows, a);
+            else
+                hipLaunchKernelGGL((box_rows_tiled_kernel<3, false>), dim3(row_blocks), dim3(64), 0, stream, (const void *)(d_px + (size_t)first * image_stride), m, h, w,
+                                   channels, row_stride, image_stride, win_rows, a);
             hipLaunchKernelGGL(box_cols_kernel, dim3((unsigned)(((uint64_t)m * w + 63) / 64)), dim3(64), 0, stream, a, b, m, h, w, win_cols);
             float *kept = a;  // [m][h][64]; plane a has been consumed by the column pass
-            hipLaunchKernelGGL((box_rows_tiled_kernel<false, true>), dim3(row_blocks), dim3(64), 0, stream, (const void *)b, m, h, w, 1u, (size_t)0, (size_t)0, win_rows, kept);
+            hipLaunchKernelGGL((box_rows_tiled_kernel<0, true>), dim3(row_blocks), dim3(64), 0, stream, (const void *)b, m, h, w, 1u, (size_t)0, (size_t)0, win_rows, kept);
             hipLaunchKernelGGL(tail_sampled_kernel, dim3(m), dim3(64), 0, stream, kept, m, h, win_cols, d_hash ? d_hash + (size_t)first * 32 : nullptr,
                                d_quality ? d_quality + first : nullptr, d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr,
                                d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr);

@@ -147,56 +147,139 @@ __device__ __forceinline__ int32_t luma_at(const uint8_t *p)
 }
 
 constexpr int RZ_TW = 64;      // output columns per workgroup
-constexpr int RZ_KREG = 8;     // window lengths up to this keep their coefficients in registers
 
+// luma of pixel i of a run of pixels held as dwords (static byte positions)
 template <int CH>
+__device__ __forceinline__ int32_t luma_of(const uint32_t *d, int i)
+{
+    const int B = i * CH;
+    const uint32_t r = (d[B >> 2] >> (8 * (B & 3))) & 0xFFu;
+    if (CH == 1) return (int32_t)r;
+    const uint32_t g = (d[(B + 1) >> 2] >> (8 * ((B + 1) & 3))) & 0xFFu, b = (d[(B + 2) >> 2] >> (8 * ((B + 2) & 3))) & 0xFFu;
+    return (int32_t)((299u * r + 587u * g + 114u * b + 500u) / 1000u);
+}
+
+// luma of pixel i of a row staged in LDS (byte reads)
+template <int CH>
+__device__ __forceinline__ int32_t luma_lds(const uint8_t *p, int i)
+{
+    if (CH == 1) return p[i];
+    return (int32_t)((299u * p[i * CH] + 587u * p[i * CH + 1] + 114u * p[i * CH + 2] + 500u) / 1000u);
+}
+
+// WMAX: the horizontal window if it is 3, 5 or 7 (sources up to 6 x the thumbnail: every tap and its weight unrolled), 0: any window.
+// Horizontal pass: a wave takes RB input rows at a time; the part of each row this column tile needs is fetched as whole aligned dwords, lane =
+// dword (adjacent lanes, adjacent addresses: an output's own taps start every ~2.5 bytes, which the memory pipe takes almost lane by lane),
+// into the wave's own LDS row buffers, and the taps are read from there.  The wave index is made scalar, so row numbers, row pointers and the
+// vertical tables are scalar too.  NIT: dwords per lane and staged row (the host picks the instantiation that covers raw_pitch).
+template <int CH, int WMAX, int NIT>
 __global__ void __launch_bounds__(256) resize_fused_kernel(const uint8_t *__restrict__ px, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride,
-                                                           uint32_t nw, uint32_t nh, DevAxis ax, DevAxis ay, uint32_t th, uint32_t tile_rows,
+                                                           uint32_t nw, uint32_t nh, DevAxis ax, DevAxis ay, uint32_t th, uint32_t tile_rows, uint32_t raw_pitch,
                                                            uint8_t *__restrict__ dst)
 {
-    extern __shared__ uint8_t rz_tile[];  // [tile_rows][RZ_TW]
-    const uint32_t lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const uint32_t img = blockIdx.z, r0 = blockIdx.y * th, r1 = min(r0 + th, nh), o = blockIdx.x * RZ_TW + lane;
+    extern __shared__ __attribute__((aligned(16))) uint8_t rz_tile[];  // [tile_rows][RZ_TW], then [4 waves][RB][raw_pitch] row buffers
+    constexpr int RB = 4;  // rows in flight per wave
+    const uint32_t lane = threadIdx.x & 63, sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t img = blockIdx.z, r0 = blockIdx.y * th, r1 = min(r0 + th, nh), c0 = blockIdx.x * RZ_TW, o = c0 + lane;
     const uint32_t in0 = ay.start[r0];
     uint32_t in1 = ay.start[r1 - 1] + ay.size[r1 - 1];
     in1 = min(min(in1, h), in0 + tile_rows);  // (the host sized tile_rows as the maximum over the row tiles: the clamp never bites)
-    if (o < nw) {
-        const uint32_t xs = ax.start[o], xn = ax.size[o];
-        const int16_t *k = ax.coef + (size_t)o * ax.window;
-        const uint8_t *base = px + (size_t)img * image_stride + (size_t)xs * CH;
+    uint8_t *rowbuf = rz_tile + ((tile_rows * RZ_TW + 15u) & ~15u) + sub * RB * raw_pitch;
+    {
+        const uint32_t c_last = min(c0 + RZ_TW, nw) - 1;
+        const uint32_t x_lo = ax.start[c0], x_hi = min(ax.start[c_last] + ax.size[c_last], w);  // source columns of this tile
+        const uint32_t oc = min(o, nw - 1);
+        const uint32_t xs = ax.start[oc], xn = ax.size[oc];
+        const int16_t *k = ax.coef + (size_t)oc * ax.window;
+        int32_t kk[WMAX ? WMAX : 1];
+#pragma unroll
+        for (int i = 0; i < WMAX; i++) kk[i] = (uint32_t)i < xn ? (int32_t)k[i] : 0;  // (absent taps carry weight 0; their bytes are whatever follows in the buffer)
         const int32_t half = 1 << (ax.precision - 1);
-        if (xn <= (uint32_t)RZ_KREG) {
-            int32_t kk[RZ_KREG];
+        const uint8_t *img_base = px + (size_t)img * image_stride + (size_t)x_lo * CH;
+        const uint32_t span_bytes = (x_hi - x_lo) * CH;
+        for (uint32_t y = in0 + sub * RB; y < in1; y += 4 * RB) {
+            uint32_t shift[RB], v[RB][NIT];
 #pragma unroll
-            for (int i = 0; i < RZ_KREG; i++) kk[i] = (uint32_t)i < xn ? (int32_t)k[i] : 0;
-            for (uint32_t y = in0 + sub; y < in1; y += 4) {
-                const uint8_t *row = base + (size_t)y * row_stride;
-                int32_t ss = half;
+            for (int q = 0; q < RB; q++) {  // RB x NIT independent loads, then the LDS writes
+                const uint8_t *row = img_base + (size_t)min(y + q, in1 - 1) * row_stride;
+                shift[q] = (uint32_t)(reinterpret_cast<uintptr_t>(row) & 3u);
+                const uint32_t *row4 = reinterpret_cast<const uint32_t *>(row - shift[q]);
+                const uint32_t ndw = (shift[q] + span_bytes + 3) / 4;
 #pragma unroll
-                for (int i = 0; i < RZ_KREG; i++)
-                    if ((uint32_t)i < xn) ss += luma_at<CH>(row + i * CH) * kk[i];
-                rz_tile[(y - in0) * RZ_TW + lane] = clip8(ss, ax.precision);
+                for (int it = 0; it < NIT; it++) v[q][it] = row4[min(lane + 64u * it, ndw - 1)];
             }
-        } else {
-            for (uint32_t y = in0 + sub; y < in1; y += 4) {
-                const uint8_t *row = base + (size_t)y * row_stride;
+#pragma unroll
+            for (int q = 0; q < RB; q++) {
+                uint32_t *to = reinterpret_cast<uint32_t *>(rowbuf + q * raw_pitch);
+#pragma unroll
+                for (int it = 0; it < NIT; it++)
+                    if ((lane + 64u * it) * 4 < raw_pitch) to[lane + 64u * it] = v[q][it];
+            }
+            __builtin_amdgcn_wave_barrier();  // the wave reads back what the wave wrote: program order in the LDS queue is enough, the compiler must keep it
+#pragma unroll
+            for (int q = 0; q < RB; q++) {
+                const uint8_t *taps = rowbuf + q * raw_pitch + shift[q] + (xs - x_lo) * CH;
                 int32_t ss = half;
-                for (uint32_t i = 0; i < xn; i++) ss += luma_at<CH>(row + (size_t)i * CH) * (int32_t)k[i];
-                rz_tile[(y - in0) * RZ_TW + lane] = clip8(ss, ax.precision);
+                if (WMAX) {
+                    // the taps' bytes as aligned dwords + a byte shift: one byte read per tap and channel costs an LDS pass each (lanes that
+                    // want different bytes of one dword are served one after the other), dword reads of neighbouring lanes are one pass
+                    constexpr int ND = WMAX ? (WMAX * CH + 3) / 4 : 1;
+                    const uint32_t at = (uint32_t)(taps - rz_tile), sh = at & 3u;
+                    const uint32_t *t4 = reinterpret_cast<const uint32_t *>(rz_tile + (at & ~3u));
+                    uint32_t raw[ND + 1], d[ND];
+#pragma unroll
+                    for (int j = 0; j <= ND; j++) raw[j] = t4[j];
+#pragma unroll
+                    for (int j = 0; j < ND; j++) d[j] = __builtin_amdgcn_alignbyte(raw[j + 1], raw[j], sh);
+#pragma unroll
+                    for (int i = 0; i < WMAX; i++) ss += luma_of<CH>(d, i) * kk[i];
+                } else {
+                    for (uint32_t i = 0; i < xn; i++) ss += luma_lds<CH>(taps, (int)i) * (int32_t)k[i];
+                }
+                if (y + q < in1) rz_tile[(y + q - in0) * RZ_TW + lane] = clip8(ss, ax.precision);
             }
         }
     }
     __syncthreads();
     if (o < nw) {
         const int32_t half = 1 << (ay.precision - 1);
-        for (uint32_t r = r0 + sub; r < r1; r += 4) {
-            const uint32_t ys = ay.start[r] - in0, yn = ay.size[r];
+        for (uint32_t r = r0 + sub; r < r1; r += 4) {  // r is the same for the whole wave: start, size and weights come through the scalar cache
+            const uint32_t ys = ay.start[r] - in0, yn = min(ay.size[r], tile_rows - min(ys, tile_rows));
             const int16_t *k = ay.coef + (size_t)r * ay.window;
+            const uint8_t *col = rz_tile + ys * RZ_TW + lane;
             int32_t ss = half;
-            for (uint32_t i = 0; i < yn && ys + i < tile_rows; i++) ss += (int32_t)rz_tile[(ys + i) * RZ_TW + lane] * (int32_t)k[i];
+            for (uint32_t i = 0; i < yn; i++) ss += (int32_t)col[i * RZ_TW] * (int32_t)k[i];
             dst[((size_t)img * nh + r) * nw + o] = clip8(ss, ay.precision);
         }
     }
+}
+
+template <int CH, int NIT>
+void launch_resize_fused_n(dim3 grid, size_t lds, hipStream_t stream, const uint8_t *src, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride, uint32_t nw,
+                           uint32_t nh, const DevAxis &dx, const DevAxis &dy, uint32_t th, uint32_t tile_rows, uint32_t raw_pitch, uint8_t *dst)
+{
+    switch (dx.window) {
+    case 3: hipLaunchKernelGGL((resize_fused_kernel<CH, 3, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst); break;
+    case 5: hipLaunchKernelGGL((resize_fused_kernel<CH, 5, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst); break;
+    case 7: hipLaunchKernelGGL((resize_fused_kernel<CH, 7, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst); break;
+    default: hipLaunchKernelGGL((resize_fused_kernel<CH, 0, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst); break;
+    }
+}
+
+constexpr int RZ_NIT_MAX = 8;  // staged rows of up to 8 x 256 bytes
+
+template <int CH>
+void launch_resize_fused(dim3 grid, size_t lds, hipStream_t stream, const uint8_t *src, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride, uint32_t nw,
+                         uint32_t nh, const DevAxis &dx, const DevAxis &dy, uint32_t th, uint32_t tile_rows, uint32_t raw_pitch, uint8_t *dst)
+{
+    const uint32_t nit = (raw_pitch / 4 + 63) / 64;
+#define RZ_GO(N) launch_resize_fused_n<CH, N>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst)
+    if (nit <= 1) RZ_GO(1);
+    else if (nit <= 2) RZ_GO(2);
+    else if (nit <= 3) RZ_GO(3);
+    else if (nit <= 4) RZ_GO(4);
+    else RZ_GO(RZ_NIT_MAX);
+#undef RZ_GO
 }
 
 }  // namespace
@@ -275,9 +358,19 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
     uint32_t nw, nh;
     rph_pdq_target_dimensions(w, h, RPH_PDQ_MAX_DIM, &nw, &nh);  // pdqhash.rs:183
     DevAxis dx, dy;
-    const DevAxisOwner *oy = nullptr;
+    const DevAxisOwner *ox = nullptr, *oy = nullptr;
     int rc;
-    if ((rc = device_axis(ctx, w, nw, dx)) != RPH_OK || (rc = device_axis(ctx, h, nh, dy, &oy)) != RPH_OK) return rc;
+    if ((rc = device_axis(ctx, w, nw, dx, &ox)) != RPH_OK || (rc = device_axis(ctx, h, nh, dy, &oy)) != RPH_OK) return rc;
+    // (the second lookup may have emptied a full cache and with it the first one's entry: look both up again, now both are there or fit)
+    if ((rc = device_axis(ctx, w, nw, dx, &ox)) != RPH_OK || (rc = device_axis(ctx, h, nh, dy, &oy)) != RPH_OK) return rc;
+    // widest stretch of source columns a tile of RZ_TW output columns needs -> bytes per staged row (+ 3 alignment bytes, whole dwords, 16-byte pitch)
+    uint32_t span = 0;
+    for (uint32_t c0 = 0; c0 < nw; c0 += RZ_TW) {
+        const uint32_t c1 = std::min(c0 + (uint32_t)RZ_TW, nw) - 1;
+        span = std::max(span, std::min(ox->h_start[c1] + ox->h_size[c1], w) - ox->h_start[c0]);
+    }
+    // (+ the widest window once more: taps of weight 0 behind an output's last real one are still read from the row buffer)
+    const uint32_t raw_pitch = (uint32_t)((((size_t)span + (size_t)dx.window) * channels + 3 + 3 + 8 + 15) & ~(size_t)15);
 
     // the fused kernel: rows of output per workgroup such that the input rows they need fit a 32 KB tile
     uint32_t th = 16, tile_rows = 0;
@@ -290,10 +383,10 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
         }
         if ((size_t)tile_rows * RZ_TW <= 32768 || th == 1) break;
     }
-    const bool fused = may_fuse && (size_t)tile_rows * RZ_TW <= 32768 && (nh + th - 1) / th <= 65535;
+    const bool fused = may_fuse && (size_t)tile_rows * RZ_TW <= 32768 && (nh + th - 1) / th <= 65535 && raw_pitch <= (uint32_t)RZ_NIT_MAX * 256;
 
     const size_t full = fused ? 0 : (size_t)w * h, tmp = fused ? 0 : (size_t)nw * h, small = (size_t)nw * nh;
-    uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)256 << 20) / (fused ? small * 5 : full));  // (small * 5: the hasher's u8 + f32 planes)
+    uint32_t chunk = (uint32_t)std::max<size_t>(1, (fused ? (size_t)1 << 30 : (size_t)256 << 20) / (fused ? small * 4 : full));  // (fused: as many images as the hasher takes per launch)
     chunk = std::min(std::min(chunk, n), 65535u);
     const size_t need = (full + tmp + small) * chunk;
     if (ctx->rz_bytes < need) {
@@ -313,13 +406,13 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
         if (fused) {
             const dim3 grid((nw + RZ_TW - 1) / RZ_TW, (nh + th - 1) / th, m);
             const uint8_t *src = d_px + (size_t)first * image_stride;
-            const size_t lds = (size_t)tile_rows * RZ_TW;
+            const size_t lds = (((size_t)tile_rows * RZ_TW + 15) & ~(size_t)15) + (size_t)4 * 4 * raw_pitch;
             if (channels == 1)
-                hipLaunchKernelGGL(resize_fused_kernel<1>, grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, p_small);
+                launch_resize_fused<1>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small);
             else if (channels == 3)
-                hipLaunchKernelGGL(resize_fused_kernel<3>, grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, p_small);
+                launch_resize_fused<3>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small);
             else
-                hipLaunchKernelGGL(resize_fused_kernel<4>, grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, p_small);
+                launch_resize_fused<4>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small);
         } else {
         hipLaunchKernelGGL(luma_u8_kernel, dim3(grid_for((uint64_t)m * full)), dim3(256), 0, stream, d_px + (size_t)first * image_stride, m, w,
                            h, channels, row_stride, image_stride, p_luma);
