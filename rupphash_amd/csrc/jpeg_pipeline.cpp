@@ -548,7 +548,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     // enough for each to still fill the device's lanes (16 GB of coefficients = 20 000 images of 512x512); a smaller call is one chunk.
     // The walk of a chunk takes as long as its longest file (~0.65 us per entropy byte: 21 ms for 29 KB files, 236 ms for 366 KB photos)
     // however few files it has, and walks of different chunks only overlap pairwise (two lanes): small files are cut into four chunks
-    // for the pipelining, photo-sized files into two so that the walks are not paid four times.
+    // for the pipelining, files whose lanes have long streams (photos without markers, segments switched off) into two so that the walks are
+    // not paid four times.
     size_t max_len = 0;  // longest stream one lane will walk: a file, or one restart interval of it (as the frame header announces them)
     for (uint32_t g : idx) {
         const rphj::Frame &f = jobs[g].frame;
