@@ -372,11 +372,14 @@ int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int fla
  *                                compressed bytes cross PCIe; the walk of one file is serial (milliseconds), so this pays from
  *                                thousands of files per call;
  *   RPH_JPEG_ENTROPY_AUTO (2)    default: device from 2048 lanes per call (a sequential file is one lane, or one per restart
- *                                interval when it has restart markers), host below.
- * Progressive files are always decoded by the host threads.  Same results either way. */
+ *                                interval when it has restart markers, or one per segment of a long stream without them; a
+ *                                progressive file is one lane), host below;
+ *   RPH_JPEG_ENTROPY_DEVICE_SEQUENTIAL (3)  as DEVICE, but progressive files stay with the host threads (tests, A/B timing).
+ * Same results either way. */
 #define RPH_JPEG_ENTROPY_HOST 0
 #define RPH_JPEG_ENTROPY_DEVICE 1
 #define RPH_JPEG_ENTROPY_AUTO 2
+#define RPH_JPEG_ENTROPY_DEVICE_SEQUENTIAL 3
 int rph_jpeg_set_entropy(rph_ctx *ctx, int where);
 /* Tuning of the device walk for streams WITHOUT restart markers: from min_stream_bytes of entropy-coded data (default 65536) a
  * stream is cut into segments of segment_bytes (default 1024; a multiple of 4 in 64 .. 65536; 0 = never) that find their

@@ -687,8 +687,9 @@ int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, 
                    std::vector<uint32_t> *restart_marks)
 {
     if (restart_marks) restart_marks->clear();
-    if (!f.have_sof || f.progressive) return RPH_ERR_UNSUPPORTED;
-    plan = StreamPlan();
+    if (!f.have_sof) return RPH_ERR_UNSUPPORTED;
+    plan.n_scans = 0;
+    plan.prog.clear();
     TableSpec dc[4], ac[4];
     bool dc_present[4] = {false, false, false, false}, ac_present[4] = {false, false, false, false};
     uint32_t dc_id[4], ac_id[4];  // interned lazily, when a scan uses the table
@@ -751,30 +752,53 @@ int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, 
             if (n >= 12 && memcmp(p, "Adobe", 5) == 0) f.adobe_transform = p[11];
             break;
         case 0xDA: {
-            if (plan.n_scans == 4) return RPH_ERR_UNSUPPORTED;
-            ScanPlan &sc = plan.scan[plan.n_scans];
+            if (plan.n_scans == (f.progressive ? MAX_PROG_SCANS : 4)) return RPH_ERR_UNSUPPORTED;
+            if (f.progressive && f.restart_interval) return RPH_ERR_UNSUPPORTED;  // (rare; the host decoder takes such a file)
+            ScanPlan local;
+            if (f.progressive) plan.prog.push_back(local);
+            ScanPlan &sc = f.progressive ? plan.prog.back() : plan.scan[plan.n_scans];
+            sc = local;
             if (n < 1) return RPH_ERR_INVALID_ARG;
             sc.ns = p[0];
             if (sc.ns < 1 || sc.ns > f.ncomp || n < 1 + 2 * sc.ns + 3) return RPH_ERR_INVALID_ARG;
+            bool need_dc = true, need_ac = true;
+            if (f.progressive) {  // T.81 G.1.1.1
+                const uint8_t *q = p + 1 + 2 * sc.ns;
+                sc.ss = q[0];
+                sc.se = q[1];
+                sc.ah = q[2] >> 4;
+                sc.al = q[2] & 15;
+                if (sc.ss > sc.se || sc.se > 63 || sc.al > 13) return RPH_ERR_INVALID_ARG;
+                if (sc.ss == 0 && sc.se != 0) return RPH_ERR_INVALID_ARG;
+                if (sc.ss != 0 && sc.ns != 1) return RPH_ERR_INVALID_ARG;
+                need_dc = sc.ss == 0 && sc.ah == 0;
+                need_ac = sc.ss != 0;
+            }
             for (int i = 0; i < sc.ns; i++) {
                 int c = 0;
                 while (c < f.ncomp && f.comp[c].id != p[1 + 2 * i]) c++;
-                if (c == f.ncomp || (done_mask >> c) & 1) return RPH_ERR_INVALID_ARG;  // a component is coded once in a sequential file
+                if (c == f.ncomp) return RPH_ERR_INVALID_ARG;
+                if (f.progressive) {
+                    for (int j = 0; j < i; j++)
+                        if (sc.ci[j] == c) return RPH_ERR_INVALID_ARG;
+                } else if ((done_mask >> c) & 1) {
+                    return RPH_ERR_INVALID_ARG;  // a component is coded once in a sequential file
+                }
                 done_mask |= 1u << c;
                 sc.ci[i] = (uint8_t)c;
                 const int td = p[2 + 2 * i] >> 4, ta = p[2 + 2 * i] & 15;
-                if (td > 3 || ta > 3 || !dc_present[td] || !ac_present[ta]) return RPH_ERR_INVALID_ARG;
-                if (!dc_known[td]) {
+                if (td > 3 || ta > 3 || (need_dc && !dc_present[td]) || (need_ac && !ac_present[ta])) return RPH_ERR_INVALID_ARG;
+                if (need_dc && !dc_known[td]) {
                     dc_id[td] = intern(store, dc[td]);
                     dc_known[td] = true;
                 }
-                if (!ac_known[ta]) {
+                if (need_ac && !ac_known[ta]) {
                     ac_id[ta] = intern(store, ac[ta]);
                     ac_known[ta] = true;
                 }
-                if (dc_id[td] == UINT32_MAX || ac_id[ta] == UINT32_MAX) return RPH_ERR_INVALID_ARG;
-                sc.dc[i] = dc_id[td];
-                sc.ac[i] = ac_id[ta];
+                if ((need_dc && dc_id[td] == UINT32_MAX) || (need_ac && ac_id[ta] == UINT32_MAX)) return RPH_ERR_INVALID_ARG;
+                sc.dc[i] = need_dc ? dc_id[td] : 0;
+                sc.ac[i] = need_ac ? ac_id[ta] : 0;
             }
             sc.restart_interval = f.restart_interval;
             sc.stream_off = (uint32_t)(o - out);
@@ -791,7 +815,7 @@ int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, 
         default: break;
         }
     }
-    if (plan.n_scans == 0 || done_mask != (1u << f.ncomp) - 1) return RPH_ERR_INVALID_ARG;
+    if (plan.n_scans == 0 || (!f.progressive && done_mask != (1u << f.ncomp) - 1)) return RPH_ERR_INVALID_ARG;
     if (f.ncomp == 3 && f.adobe_transform == 0) return RPH_ERR_UNSUPPORTED;
     for (int c = 0; c < f.ncomp; c++)
         if (!f.qt_present[f.comp[c].tq]) return RPH_ERR_INVALID_ARG;

@@ -65,18 +65,23 @@ struct ScanPlan {
     uint32_t restart_interval = 0;            // as defined when the scan starts
     uint8_t ns = 0, ci[3] = {0, 0, 0};
     uint32_t dc[3] = {0, 0, 0}, ac[3] = {0, 0, 0};  // table ids (from the caller's interning function) per component of the scan
+    uint8_t ss = 0, se = 63, ah = 0, al = 0;        // progressive scans: spectral selection, successive approximation (T.81 G.1)
 };
+constexpr int MAX_PROG_SCANS = 64;
 struct StreamPlan {
     int n_scans = 0;
-    ScanPlan scan[4];
+    ScanPlan scan[4];            // sequential files
+    std::vector<ScanPlan> prog;  // progressive files: all their scans, in file order (n_scans of them)
 };
 // Gives a table an id; equal tables get equal ids (the device keeps one lookup table per id).  UINT32_MAX = not a valid Huffman table.
 typedef uint32_t (*InternTable)(void *store, const TableSpec &t);
 
-// Sequential (SOF0 / SOF1) files only.  Walks the markers of a file whose frame `f` came from parse_frame, copies the entropy-coded
+// Walks the markers of a file whose frame `f` came from parse_frame, copies the entropy-coded
 // bytes of each scan to `out` with the byte stuffing undone (0xFF00 -> 0xFF) and the RSTn markers dropped (the decoder byte-aligns
-// every restart_interval MCUs instead), 32 zero bytes after each scan; at most `cap` bytes (len + 160 always suffices).
-// RPH_ERR_UNSUPPORTED: progressive, or more than 4 scans -- the caller uses decode_coefficients for that file.
+// every restart_interval MCUs instead), 32 zero bytes after each scan; at most `cap` bytes (len + 160 always suffices for a sequential
+// file, len + 160 + 32 * MAX_PROG_SCANS for a progressive one).
+// RPH_ERR_UNSUPPORTED: a sequential file of more than 4 scans, a progressive one of more than MAX_PROG_SCANS or with restart intervals
+// -- the caller uses decode_coefficients for that file.
 // `restart_marks` (nullable): for a file of ONE scan with a restart interval, the offsets (from the scan's first byte in `out`) at which
 // the restart intervals after the first begin -- every interval is an independent bit stream (predictions reset, byte aligned), so
 // the device can give each a lane of its own.  Left empty when the marks do not add up to ceil(MCUs / interval) - 1.

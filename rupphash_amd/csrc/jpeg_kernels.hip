@@ -508,6 +508,301 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Progressive files (T.81 G.1.2), one per lane: the scans of a file run one after the other in the lane, each over the file's whole
+// block grid -- first DC (difference coding, value << Al), DC refinement (one bit per block), first AC of a band (runs, end-of-band
+// runs over blocks), AC refinement (a correction bit for every coefficient that is already nonzero, new +-1 values in between).
+// First scans only write.  DC refinement ORs its bit in with a fire-and-forget atomic (nothing waits for the old value).  AC
+// refinement must see what the earlier scans left: the lane keeps the block it works on in LDS (fetched as eight 16-byte loads, the
+// next block already in flight in registers) and stores the coefficients it changes one by one.  One step of the loop = one symbol
+// or one coefficient position, so the lanes of a wave stay together whatever their blocks hold.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct BitR {
+    const uint8_t *sbase;
+    uint32_t limit, q0n, woff;
+    uint64_t acc, q0;
+    W2 q1;
+    int nb;
+    __device__ __forceinline__ W2 load8(uint32_t at) const { return *reinterpret_cast<const W2 *>(sbase + (at < limit ? at : limit)); }
+    static __device__ __forceinline__ uint64_t be64(W2 v) { return ((uint64_t)__builtin_bswap32(v.x) << 32) | __builtin_bswap32(v.y); }
+    __device__ __forceinline__ void init(const uint8_t *sp, uint32_t slen)
+    {
+        const uint32_t lead = (uint32_t)((uintptr_t)sp & 3);
+        sbase = sp - lead;
+        limit = ((slen + lead + 3) & ~3u) + 8;  // 32 zero bytes lie behind the scan
+        acc = (uint64_t)(__builtin_bswap32(*reinterpret_cast<const uint32_t *>(sbase)) << (8 * lead)) << 32;
+        nb = 32 - 8 * (int)lead;
+        q0 = be64(load8(4));
+        q1 = load8(12);
+        q0n = 64;
+        woff = 20;
+    }
+    __device__ __forceinline__ void fill()  // at least 32 valid bits
+    {
+        if (nb < 32) {
+            acc |= (q0 >> 32) << (32 - nb);
+            nb += 32;
+            q0 <<= 32;
+            q0n -= 32;
+            if (q0n == 0) {
+                q0 = be64(q1);
+                q0n = 64;
+                q1 = load8(woff);
+                woff += 8;
+            }
+        }
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t n)  // n in 1..31 bits, MSB first
+    {
+        const uint32_t v = (uint32_t)(acc >> (64 - n));
+        acc <<= n;
+        nb -= (int)n;
+        return v;
+    }
+    // one Huffman symbol; 0x100 = not a code of this table
+    __device__ __forceinline__ uint32_t symbol(const rphj::DeviceLut *L)
+    {
+        const uint32_t e = L->look[(uint32_t)(acc >> 54)];
+        uint32_t len, sym;
+        if (e) {
+            len = e >> 8;
+            sym = e & 255;
+        } else {
+            const int32_t win = (int32_t)(acc >> 48);
+            uint32_t l = 11;
+            while (l <= 16 && win >= L->maxcode[l]) l++;
+            if (l > 16) return 0x100;
+            len = l;
+            sym = L->sym[(uint32_t)((win >> (16 - l)) + L->delta[l]) & 255];
+        }
+        acc <<= len;
+        nb -= (int)len;
+        return sym;
+    }
+};
+
+template <int LDS_TABLES>
+__global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const PScan *__restrict__ pscans,
+                                                       const uint32_t *__restrict__ order, uint32_t n, const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts,
+                                                       int16_t *__restrict__ coef, uint8_t *__restrict__ status)
+{
+    __shared__ uint8_t zz[80];
+    __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
+    __shared__ uint32_t s_blk[32 * 64];  // the block a lane refines: dword d of lane l at [d * 64 + l] (natural order, two coefficients per dword)
+    for (int t = threadIdx.x; t < 80; t += 64) zz[t] = c_zigzag[t];
+    if (LDS_TABLES > 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(g_luts);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_luts);
+        const uint32_t words = n_luts * (uint32_t)(sizeof(rphj::DeviceLut) / 16);
+        for (uint32_t t = threadIdx.x; t < words; t += 64) dst[t] = src[t];
+    }
+    const rphj::DeviceLut *luts = LDS_TABLES > 0 ? s_luts : g_luts;
+    __syncthreads();
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
+    if (slot >= n) return;
+    const uint32_t ii = order[slot];
+    const HImage *im = imgs + ii;
+    const uint64_t img_fb = im->first_block;
+    uint32_t bad = 0;
+    for (uint32_t sci = 0; sci < im->pscan_count && !bad; sci++) {
+        const PScan P = pscans[im->pscan_first + sci];
+        BitR b;
+        b.init(streams + im->stream_base + P.off, P.len);
+        const uint32_t al = P.al;
+        if (P.ss == 0) {
+            // ---- DC scan: MCU order (one component: its own block grid, T.81 A.2.2)
+            const uint32_t ns = P.ns;
+            const HComp *c0 = &im->comp[P.ci[0]], *c1 = &im->comp[P.ci[ns > 1 ? 1 : 0]], *c2 = &im->comp[P.ci[ns > 2 ? 2 : 0]];
+            const uint32_t H0 = ns == 1 ? 1 : c0->H, V0 = ns == 1 ? 1 : c0->V, BW0 = c0->blocks_w, FB0 = c0->first_block;
+            const uint32_t H1 = c1->H, V1 = c1->V, BW1 = c1->blocks_w, FB1 = c1->first_block;
+            const uint32_t H2 = c2->H, V2 = c2->V, BW2 = c2->blocks_w, FB2 = c2->first_block;
+            const rphj::DeviceLut *D0 = luts + P.dc[0], *D1 = luts + P.dc[ns > 1 ? 1 : 0], *D2 = luts + P.dc[ns > 2 ? 2 : 0];
+            const uint32_t MX = ns == 1 ? c0->real_bw : im->mcus_x, MY = ns == 1 ? c0->real_bh : im->mcus_y;
+            uint32_t i = 0, h = 0, v = 0, mx = 0, my = 0;
+            int p0 = 0, p1 = 0, p2 = 0;
+            bool done = MX == 0 || MY == 0;
+            while (!done) {
+                b.fill();
+                const uint32_t Hc = sel3(i, H0, H1, H2), Vc = sel3(i, V0, V1, V2), BWc = sel3(i, BW0, BW1, BW2), FBc = sel3(i, FB0, FB1, FB2);
+                const uint64_t base = (img_fb + FBc + (uint64_t)(my * Vc + v) * BWc + (mx * Hc + h)) * 64;
+                if (P.ah == 0) {
+                    const uint32_t s = b.symbol(sel3(i, D0, D1, D2));
+                    if (s > 15) {
+                        bad = 1;
+                        break;
+                    }
+                    int val = 0;
+                    if (s) {
+                        const uint32_t raw = b.take(s);
+                        val = raw < (1u << (s - 1)) ? (int)raw - (int)((1u << s) - 1) : (int)raw;
+                    }
+                    const int pv = sel3(i, p0, p1, p2) + val;
+                    p0 = i == 0 ? pv : p0;
+                    p1 = i == 1 ? pv : p1;
+                    p2 = i == 2 ? pv : p2;
+                    coef[base] = (int16_t)(pv * (1 << al));
+                } else if (b.take(1)) {
+                    atomicOr(reinterpret_cast<unsigned int *>(coef + base), 1u << al);  // coefficient 0 is the low half of the block's first dword
+                }
+                if (++h == Hc) {
+                    h = 0;
+                    if (++v == Vc) {
+                        v = 0;
+                        if (++i == ns) {
+                            i = 0;
+                            if (++mx == MX) {
+                                mx = 0;
+                                if (++my == MY) done = true;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            // ---- AC scan: one component, its own block grid in raster order
+            const HComp *c = &im->comp[P.ci[0]];
+            const uint32_t MX = c->real_bw, MY = c->real_bh, BW = c->blocks_w, total = MX * MY;
+            const uint64_t comp_base = img_fb + c->first_block;
+            const rphj::DeviceLut *A = luts + P.ac;
+            const uint32_t ss = P.ss, se = P.se;
+            auto block_at = [&](uint32_t bl) -> uint64_t { return (comp_base + (uint64_t)(bl / MX) * BW + bl % MX) * 64; };
+            if (P.ah == 0) {
+                // first pass over the band: one symbol per step
+                uint32_t bl = 0, k = ss;
+                uint64_t base = total ? block_at(0) : 0;
+                const uint64_t max_it = (uint64_t)total * 65 + 8;
+                for (uint64_t it = 0; bl < total && it < max_it; it++) {
+                    b.fill();
+                    const uint32_t rs = b.symbol(A);
+                    if (rs > 255) {
+                        bad = 1;
+                        break;
+                    }
+                    const uint32_t r = rs >> 4, s = rs & 15;
+                    uint32_t adv = 0;  // blocks to move on by
+                    if (s == 0) {
+                        if (r == 15) {
+                            k += 16;
+                            if (k > se) adv = 1;
+                        } else {  // end of band for this block and the next (1 << r) - 1 + bits
+                            uint32_t run = (1u << r) - 1;
+                            if (r) run += b.take(r);
+                            adv = 1 + run;
+                        }
+                    } else {
+                        k += r;
+                        if (k > 63) {
+                            bad = 1;
+                            break;
+                        }
+                        const uint32_t raw = b.take(s);
+                        const int val = raw < (1u << (s - 1)) ? (int)raw - (int)((1u << s) - 1) : (int)raw;
+                        coef[base + zz[k]] = (int16_t)(val * (1 << al));
+                        k++;
+                        if (k > se) adv = 1;
+                    }
+                    if (adv) {
+                        bl = adv > total - bl ? total : bl + adv;
+                        k = ss;
+                        if (bl < total) base = block_at(bl);
+                    }
+                }
+                if (bl < total) bad = 1;
+            } else {
+                // refinement of the band: mode 0 = a symbol is due, 1 = stepping over r zero-history coefficients (then placing `value`),
+                // 2 = the block lies in an end-of-band run (correction bits only)
+                const int p1 = 1 << al, m1 = -(1 << al);
+                uint32_t bl = 0, k = ss, mode = 0, eobrun = 0;
+                int r = 0, value = 0;
+                uint64_t base = 0;
+                uint4 pf[8];
+                auto fetch = [&](uint32_t blk) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(coef + block_at(blk));
+#pragma unroll
+                    for (int j = 0; j < 8; j++) pf[j] = src[j];
+                };
+                auto enter = [&](uint32_t blk) {  // the prefetched block becomes the current one; the next is requested
+                    base = block_at(blk);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        s_blk[(4 * j + 0) * 64 + lane] = pf[j].x;
+                        s_blk[(4 * j + 1) * 64 + lane] = pf[j].y;
+                        s_blk[(4 * j + 2) * 64 + lane] = pf[j].z;
+                        s_blk[(4 * j + 3) * 64 + lane] = pf[j].w;
+                    }
+                    if (blk + 1 < total) fetch(blk + 1);
+                    k = ss;
+                    mode = eobrun > 0 ? 2 : 0;
+                };
+                auto coef_at = [&](uint32_t nat) -> int {
+                    const uint32_t d = s_blk[(nat >> 1) * 64 + lane];
+                    return (int)(int16_t)(nat & 1 ? d >> 16 : d & 0xFFFFu);
+                };
+                if (total) {
+                    fetch(0);
+                    enter(0);
+                }
+                const uint64_t max_it = (uint64_t)total * 130 + 8;
+                for (uint64_t it = 0; bl < total && it < max_it; it++) {
+                    b.fill();
+                    bool block_done = false;
+                    if (mode == 0) {
+                        const uint32_t rs = b.symbol(A);
+                        if (rs > 255) {
+                            bad = 1;
+                            break;
+                        }
+                        r = (int)(rs >> 4);
+                        const uint32_t s = rs & 15;
+                        value = 0;
+                        if (s) {
+                            if (s != 1) {
+                                bad = 1;
+                                break;
+                            }
+                            value = b.take(1) ? p1 : m1;
+                            mode = 1;
+                        } else if (r != 15) {
+                            eobrun = 1u << r;
+                            if (r) eobrun += b.take((uint32_t)r);
+                            mode = 2;
+                        } else {
+                            mode = 1;  // sixteen zero-history coefficients to step over, nothing to place
+                        }
+                    } else {
+                        const uint32_t nat = zz[k];
+                        const int cv = coef_at(nat);
+                        if (cv != 0) {  // nonzero history: one correction bit
+                            if (b.take(1) && (cv & p1) == 0) coef[base + nat] = (int16_t)(cv >= 0 ? cv + p1 : cv + m1);
+                            k++;
+                            if (k > se) block_done = true;
+                        } else if (mode == 2) {
+                            k++;
+                            if (k > se) block_done = true;
+                        } else if (--r < 0) {  // the run of zeros is through: this is the new coefficient's place
+                            if (value) coef[base + nat] = (int16_t)value;
+                            k++;
+                            mode = 0;
+                            if (k > se) block_done = true;
+                        } else {
+                            k++;
+                            if (k > se) block_done = true;
+                        }
+                    }
+                    if (block_done) {
+                        if (eobrun > 0) eobrun--;
+                        bl++;
+                        if (bl < total) enter(bl);
+                    }
+                }
+                if (bl < total) bad = 1;
+            }
+        }
+    }
+    if (bad) status[ii] = 1;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Segments of a stream without restart markers (jpeg_device.h): one lane per segment.  mode 0: decode from the segment boundary as if an
 // MCU began there, mark the MCU starts seen inside the segment, report the first one behind it.  mode 1 (validation round `round`): the
 // entry is the predecessor's `out` of the previous round; if this lane's last decode started there or saw an MCU begin there, its
@@ -756,6 +1051,19 @@ int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HIm
                            d_status);
     else
         hipLaunchKernelGGL(jpeg_huff_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_items, d_order, n_ordered, n_items, d_luts, n_luts, d_coef, d_status);
+    RPH_HIP_CHECK(hipGetLastError());
+    return RPH_OK;
+}
+
+int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const PScan *d_pscans, const uint32_t *d_order, uint32_t n,
+                         const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status)
+{
+    if (n == 0) return RPH_OK;
+    const dim3 grid((n + 63) / 64);
+    if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
+        hipLaunchKernelGGL(jpeg_prog_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_order, n, d_luts, n_luts, d_coef, d_status);
+    else
+        hipLaunchKernelGGL(jpeg_prog_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_order, n, d_luts, n_luts, d_coef, d_status);
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }

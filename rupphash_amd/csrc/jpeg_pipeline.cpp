@@ -197,6 +197,9 @@ struct Job {
 
 using Jobs = std::vector<Job>;
 
+// bytes of the chunk's stream buffer a file may need (prepare_stream: 32 zero bytes behind every scan)
+inline size_t stream_cap(const Job &j) { return align_up(j.len + 160 + (j.frame.progressive ? 32 * (size_t)rphj::MAX_PROG_SCANS : 0), 16); }
+
 // Channels of the pixels the device writes for a file: Rgb8 only where the caller reads RGB (rph_jpeg_decode); a colour file that
 // only the hasher reads is written as its Rec.601 luma (a third of the bytes, and the PDQ paths start from luma anyway: Luma8 input
 // is borrowed as it is, pdqhash.rs:176; 512x512 Luma8 has its own form of the fused kernel)
@@ -607,7 +610,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             const size_t nb = (size_t)j.frame.total_blocks;
             if (last > first && (blocks + nb) * 128 > chunk_bytes) break;
             blocks += nb;
-            file_bytes += align_up(j.len + 160, 16);
+            file_bytes += stream_cap(j);
             last++;
         }
         if (blocks * 128 > region) {  // one image larger than a whole region: the host path takes it
@@ -632,7 +635,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             for (size_t i = first; i < last; i++) {
                 Job &j = jobs[idx[i]];
                 j.stream_off = off;
-                off += align_up(j.len + 160, 16);
+                off += stream_cap(j);
                 j.first_block = fb;
                 fb += j.frame.total_blocks;
             }
@@ -643,20 +646,20 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             Job &j = jobs[idx[i]];
             HImage &hi = himgs[i - first];
             memset(&hi, 0, sizeof hi);
-            j.status = rphj::prepare_stream(j.data, j.len, j.frame, j.plan, S.stream_bytes.h + j.stream_off, align_up(j.len + 160, 16), &j.stream_used, &TableStore::intern, &store, &j.marks);
+            j.status = rphj::prepare_stream(j.data, j.len, j.frame, j.plan, S.stream_bytes.h + j.stream_off, stream_cap(j), &j.stream_used, &TableStore::intern, &store, &j.marks);
             if (j.status != RPH_OK) return;
             const rphj::Frame &f = j.frame;
             hi.first_block = j.first_block;
             hi.stream_base = j.stream_off;
             hi.mcus_x = f.mcus_x;
             hi.mcus_y = f.mcus_y;
-            hi.n_scans = (uint32_t)j.plan.n_scans;
+            hi.n_scans = f.progressive ? 0u : (uint32_t)j.plan.n_scans;
             hi.ncomp = (uint32_t)f.ncomp;
             for (int c = 0; c < f.ncomp; c++) {
                 const rphj::Comp &kc = f.comp[c];
                 hi.comp[c] = HComp{kc.blocks_w, kc.real_bw, kc.real_bh, (uint32_t)kc.first_block, kc.H, kc.V};
             }
-            for (int q = 0; q < j.plan.n_scans; q++) {
+            for (int q = 0; q < (f.progressive ? 0 : j.plan.n_scans); q++) {
                 const rphj::ScanPlan &sp = j.plan.scan[q];
                 HScan &hs = hi.scan[q];
                 hs.off = sp.stream_off;
@@ -677,6 +680,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         std::vector<HItem> items;
         std::vector<uint32_t> item_len;
         std::vector<SegFile> seg_files;
+        std::vector<PScan> pscans;            // the scans of the chunk's progressive files
+        std::vector<uint32_t> prog_order;     // the progressive files (indices into the chunk), longest first
         uint32_t n_segs = 0;
         items.reserve(m);
         for (size_t i = first; i < last; i++) {
@@ -684,6 +689,19 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             if (j.status == RPH_ERR_UNSUPPORTED || j.status == RPH_ERR_CAPACITY) leftover.push_back(idx[i]);
             if (j.status != RPH_OK) continue;
             const uint32_t r = (uint32_t)(i - first);
+            if (j.frame.progressive) {  // one lane walks all scans of the file (jpeg_prog_kernel)
+                himgs[r].pscan_first = (uint32_t)pscans.size();
+                himgs[r].pscan_count = (uint32_t)j.plan.prog.size();
+                for (const rphj::ScanPlan &sp : j.plan.prog) {
+                    PScan ps;
+                    ps.off = sp.stream_off, ps.len = sp.stream_len, ps.ns = sp.ns, ps.ss = sp.ss, ps.se = sp.se, ps.ah = sp.ah, ps.al = sp.al;
+                    for (int c = 0; c < 3; c++) ps.ci[c] = sp.ci[c], ps.dc[c] = sp.dc[c];
+                    ps.ac = sp.ac[0];
+                    pscans.push_back(ps);
+                }
+                prog_order.push_back(r);
+                continue;
+            }
             if (j.marks.empty()) {
                 const rphj::ScanPlan &sp0 = j.plan.scan[0];
                 if (ctx->jpeg_seg_bytes && j.plan.n_scans == 1 && sp0.restart_interval == 0 && sp0.stream_len >= ctx->jpeg_seg_min_bytes && sp0.stream_len < ((uint32_t)1 << 28)) {
@@ -714,6 +732,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 item_len.push_back(end > off ? end - off : 0);
             }
         }
+        std::stable_sort(prog_order.begin(), prog_order.end(), [&](uint32_t a, uint32_t b) { return jobs[idx[first + a]].len > jobs[idx[first + b]].len; });
         std::vector<uint32_t> order(items.size());
         for (uint32_t t = 0; t < order.size(); t++) order[t] = t;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return item_len[a] > item_len[b]; });
@@ -729,7 +748,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         const size_t recon_bytes = m * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128);
         // (the items of the segments exist on the device only: d_meta has room for them, the upload stops before them)
         const size_t off_himg = align_up(recon_bytes, 16), off_order = off_himg + m * sizeof(HImage), off_luts = align_up(off_order + order.size() * 4, 16),
-                     off_segf = align_up(off_luts + luts.size() * sizeof(rphj::DeviceLut), 16), off_items = align_up(off_segf + seg_files.size() * sizeof(SegFile), 16),
+                     off_segf = align_up(off_luts + luts.size() * sizeof(rphj::DeviceLut), 16), off_pscan = align_up(off_segf + seg_files.size() * sizeof(SegFile), 16),
+                     off_porder = off_pscan + pscans.size() * sizeof(PScan), off_items = align_up(off_porder + prog_order.size() * 4, 16),
                      upload_bytes = off_items + items.size() * sizeof(HItem), meta_bytes = off_items + (size_t)n_items * sizeof(HItem);
         RPH_TRY(S.meta.reserve(meta_bytes));
         const size_t segwork = align_up((size_t)n_segs * sizeof(SegState), 16) + (size_t)n_segs * (ctx->jpeg_seg_bytes + 12) + 64;
@@ -747,6 +767,10 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         memcpy(S.meta.h + off_order, order.data(), order.size() * 4);
         if (!luts.empty()) memcpy(S.meta.h + off_luts, luts.data(), luts.size() * sizeof(rphj::DeviceLut));
         if (n_segs) memcpy(S.meta.h + off_segf, seg_files.data(), seg_files.size() * sizeof(SegFile));
+        if (!prog_order.empty()) {
+            memcpy(S.meta.h + off_pscan, pscans.data(), pscans.size() * sizeof(PScan));
+            memcpy(S.meta.h + off_porder, prog_order.data(), prog_order.size() * 4);
+        }
         // ---- device: streams up, zeroed coefficients, the walk, then reconstruction + hashing sub-batch by sub-batch
         const double t_desc = now_ms();
         const bool tr = trace_on();  // RPH_JPEG_TRACE: synchronise after every phase and print where the time goes (stderr)
@@ -759,7 +783,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         };
         ResView R(S.res.d, S.res_images);
         RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
-        if (n_items) {
+        if (n_items || !prog_order.empty()) {
             RPH_HIP_CHECK(hipMemcpyAsync(S.stream_bytes.d, S.stream_bytes.h, file_bytes + 64, hipMemcpyHostToDevice, s));
             RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, upload_bytes, hipMemcpyHostToDevice, s));
             lap(t_up);
@@ -773,8 +797,12 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             lap(t_seg);
             RPH_HIP_CHECK(hipMemsetAsync(d_coef, 0, blocks * 128, s));
             lap(t_zero);
-            RPH_TRY(rph_jpeg_launch_walk(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const HItem *>(S.meta.d + off_items),
-                                         reinterpret_cast<const uint32_t *>(S.meta.d + off_order), n_ordered, n_items,
+            if (n_items)
+                RPH_TRY(rph_jpeg_launch_walk(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const HItem *>(S.meta.d + off_items),
+                                             reinterpret_cast<const uint32_t *>(S.meta.d + off_order), n_ordered, n_items,
+                                             reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, R.status));
+            RPH_TRY(rph_jpeg_launch_prog(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const PScan *>(S.meta.d + off_pscan),
+                                         reinterpret_cast<const uint32_t *>(S.meta.d + off_porder), (uint32_t)prog_order.size(),
                                          reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, R.status));
             lap(t_walk);
             for (size_t q = 0; q < subs.size(); q++) {
@@ -831,7 +859,7 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
     std::vector<uint32_t> host_idx, dev_idx;
     for (uint32_t i = 0; i < n; i++) {
         const Job &j = jobs[i];
-        if (j.status == RPH_OK && !j.frame.progressive && ctx->jpeg_entropy != 0 && out.want_hash && !prepared)
+        if (j.status == RPH_OK && (!j.frame.progressive || ctx->jpeg_progressive_on_device) && ctx->jpeg_entropy != 0 && out.want_hash && !prepared)
             dev_idx.push_back(i);
         else
             host_idx.push_back(i);
@@ -976,12 +1004,13 @@ int rph_jpeg_release(rph_ctx *ctx)
 
 int rph_jpeg_set_entropy(rph_ctx *ctx, int where)
 {
-    if (!ctx || where < 0 || where > 2) {
+    if (!ctx || where < 0 || where > 3) {
         rph_set_error("rph_jpeg_set_entropy: invalid argument");
         return RPH_ERR_INVALID_ARG;
     }
     std::lock_guard<std::mutex> lock(ctx->jpeg_mu);
-    ctx->jpeg_entropy = where;
+    ctx->jpeg_entropy = where == 3 ? 1 : where;
+    ctx->jpeg_progressive_on_device = where == 3 ? 0 : 1;
     return RPH_OK;
 }
 

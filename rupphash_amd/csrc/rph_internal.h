@@ -59,6 +59,7 @@ struct rph_ctx {
     // where the Huffman streams of sequential files are decoded: 0 = host threads, 1 = device (one image per lane), 2 = automatic
     // (device from 2048 sequential files per call: the walk of one image is serial, so it needs tens of thousands of images in flight)
     int jpeg_entropy = 2;
+    int jpeg_progressive_on_device = 1;  // 0: progressive files stay with the host threads (rph_jpeg_set_entropy(ctx, 3))
     // device walk of streams without restart markers: from jpeg_seg_min_bytes of entropy data a stream is cut into segments of
     // jpeg_seg_bytes that synchronise on the device and are walked side by side (0 = never)
     uint32_t jpeg_seg_min_bytes = 65536, jpeg_seg_bytes = 1024;

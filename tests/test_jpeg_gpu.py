@@ -253,6 +253,42 @@ def test_streams_without_markers_cut_into_segments(eng, oracle, seg_bytes):
         assert ok and np.array_equal(dev["hash"][k], h)
 
 
+def test_progressive_files_walk_on_the_device(eng, oracle):
+    """progressive files (T.81 G.1.2: DC first / refinement, AC first with end-of-band runs, AC refinement with correction bits), one per
+    lane through all their scans: the reference's own progressive files, every sampling layout, gray, tiny and photo-sized, noise (long
+    runs of corrections) and flat images (long end-of-band runs); results must be the host decoder's, and the oracle's where it is asked"""
+    from PIL import Image
+
+    files = [_read(n) for n in FILES]
+    for k, (w, h, mode, ss) in enumerate([(640, 400, "RGB", 2), (333, 517, "RGB", 1), (200, 120, "RGB", 0), (97, 61, "L", 0), (1280, 854, "RGB", 2), (16, 16, "RGB", 2),
+                                          (8, 8, "L", 0), (500, 40, "RGB", 2), (5, 5, "RGB", 2), (1, 1, "L", 0), (17, 9, "RGB", 1), (512, 512, "RGB", 2), (512, 512, "L", 0)]):
+        kw = dict(quality=[30, 50, 75, 90, 97][k % 5], progressive=True)
+        if mode == "RGB":
+            kw["subsampling"] = ss
+        files.append(ju.pillow_jpeg(ju.make_image(w, h, mode, seed=190 + k), **kw))
+    rng = np.random.default_rng(13)
+    files.append(ju.pillow_jpeg(Image.fromarray(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)), quality=95, subsampling=0, progressive=True))
+    files.append(ju.pillow_jpeg(Image.fromarray(rng.integers(0, 256, (64, 64), dtype=np.uint8)), quality=100, progressive=True))
+    files.append(ju.pillow_jpeg(Image.fromarray(np.full((600, 800, 3), 77, np.uint8)), quality=90, subsampling=2, progressive=True))
+    files.append(ju.pillow_jpeg(ju.make_image(320, 240, seed=7), quality=85, subsampling=2))  # a sequential file between them
+    files = files * 3
+    eng.jpeg_set_entropy(0)
+    host = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    eng.jpeg_set_entropy(3)  # device for sequential files only: progressive ones by the host threads
+    seq_only = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    eng.jpeg_set_entropy(1)
+    dev = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    eng.jpeg_set_entropy(2)
+    assert not dev["status"].any() and np.array_equal(dev["valid"], host["valid"])
+    for other in (seq_only, dev):
+        assert np.array_equal(other["hash"], host["hash"]) and np.array_equal(other["coeffs"].view(np.uint32), host["coeffs"].view(np.uint32))
+    for k in (0, 1, 2, 3, 7, 16, 18):
+        ok, h, _, _ = _oracle_hash(oracle, oracle.jpeg_decode(files[k], 0))
+        assert ok and np.array_equal(dev["hash"][k], h), k
+    # (the 256 f32 coefficients are compared bit for bit: below 513 px every pixel of the image carries weight in them, so a single wrong
+    # DCT coefficient anywhere in such a file shows)
+
+
 def test_restart_intervals_get_a_lane_each(eng, oracle):
     """one-scan files with restart markers are walked by one lane per interval; 60 photos with an interval per MCU row are 3 000+
     lanes, so the automatic mode takes the device walk for them; hashes equal the host decoder's and the oracle's"""

@@ -21,7 +21,10 @@ static void run(const std::vector<uint8_t> &f)
     rphj::StreamPlan plan;
     std::vector<uint8_t> out(f.size() + 160);
     size_t used = 0;
-    (void)rphj::prepare_stream(f.data(), f.size(), b, plan, out.data(), out.size(), &used, intern, nullptr);
+    (void)rphj::prepare_stream(f.data(), f.size(), b, plan, out.data(), out.size(), &used, intern, nullptr);  // (too small for most progressive files: must be refused, not overrun)
+    rphj::Frame c = fr;
+    std::vector<uint8_t> out2(f.size() + 160 + 32 * (size_t)rphj::MAX_PROG_SCANS);
+    (void)rphj::prepare_stream(f.data(), f.size(), c, plan, out2.data(), out2.size(), &used, intern, nullptr);
 }
 int main(int argc, char **argv)
 {

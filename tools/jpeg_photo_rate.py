@@ -36,6 +36,11 @@ def main():
         buf = io.BytesIO()
         im.crop((k, k // 2, 1280 - (15 - k), 854 - (7 - k // 2))).save(buf, "JPEG", quality=90, subsampling=2, restart_marker_rows=1)
         with_rst.append(buf.getvalue())
+    prog = []
+    for k in range(16):  # and as progressive files (what the web serves): ten scans over every block, one lane per file
+        buf = io.BytesIO()
+        im.crop((k, k // 2, 1280 - (15 - k), 854 - (7 - k // 2))).save(buf, "JPEG", quality=90, subsampling=2, progressive=True)
+        prog.append(buf.getvalue())
     t = time.perf_counter()
     for f in variants:
         np.asarray(Image.open(io.BytesIO(f)))
@@ -43,7 +48,8 @@ def main():
     print(f"libjpeg-turbo (Pillow) full decode, 1 thread: {1 / dec:7.0f} files/s ({dec * 1e3:.2f} ms per ~1265x850 file of {len(variants[0]) / 1e3:.0f} KB)")
     for label, base, mode in [("baseline 4:2:0 q90, device entropy", variants, 1), ("same with restart intervals, device entropy", with_rst, 1),
                               ("same with restart intervals, device, n = 2048", with_rst, 2), ("baseline 4:2:0 q90, device entropy, n = 2048", variants, 2),
-                              ("baseline 4:2:0 q90, host entropy", variants, 0), ("bench.jpg as it is (progressive), host entropy", [orig], 0)]:
+                              ("baseline 4:2:0 q90, host entropy", variants, 0), ("bench.jpg as it is (progressive), host entropy", [orig], 0),
+                              ("progressive 4:2:0 q90, device entropy", prog, 1), ("progressive 4:2:0 q90, device, n = 2048", prog, 2)]:
         n = a.n if mode == 1 else (2048 if mode == 2 else min(a.n, 4000))
         files = eng.jpeg_file_list([base[k % len(base)] for k in range(n)])
         eng.jpeg_set_entropy(min(mode, 1))

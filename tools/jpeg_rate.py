@@ -57,8 +57,6 @@ def main():
             dt = time.perf_counter() - t
             assert out["valid"].all()
             print(f"   host entropy   threads={t_n:3d} n={a.n:6d}: {a.n / dt:9.0f} files/s  {mb / dt:7.1f} MB/s of JPEG  {a.n * a.size * a.size * 3 / dt / 1e9:6.2f} GB/s of pixels")
-        if kw.get("progressive"):
-            continue  # progressive files stay with the host decoder
         eng.jpeg_set_entropy(1)
         for n_dev in sorted({a.n, min(a.device_n, 20000), a.device_n}):
             big = [base[k % a.distinct] for k in range(n_dev)]
