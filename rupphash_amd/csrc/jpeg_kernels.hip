@@ -516,6 +516,9 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
 // next block already in flight in registers) and stores the coefficients it changes one by one.  One step of the loop = one symbol
 // or one coefficient position, so the lanes of a wave stay together whatever their blocks hold.
 // ---------------------------------------------------------------------------------------------------------------------------
+constexpr uint8_t ZZC[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
 struct BitR {
     const uint8_t *sbase;
     uint32_t limit, q0n, woff;
@@ -558,7 +561,18 @@ struct BitR {
         nb -= (int)n;
         return v;
     }
-    // one Huffman symbol; 0x100 = not a code of this table
+    // one Huffman symbol; 0x100 = not a code of this table.  look8: the lane's own 8-bit lookup in LDS ([prefix * 64 + lane]; 0 = longer code)
+    __device__ __forceinline__ uint32_t symbol8(const uint16_t *look8, uint32_t lane, const rphj::DeviceLut *L)
+    {
+        const uint32_t e = look8[(uint32_t)(acc >> 56) * 64 + lane];
+        if (e) {
+            const uint32_t len = e >> 8;
+            acc <<= len;
+            nb -= (int)len;
+            return e & 255;
+        }
+        return symbol(L);
+    }
     __device__ __forceinline__ uint32_t symbol(const rphj::DeviceLut *L)
     {
         const uint32_t e = L->look[(uint32_t)(acc >> 54)];
@@ -588,6 +602,9 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
     __shared__ uint8_t zz[80];
     __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
     __shared__ uint32_t s_blk[32 * 64];  // the block a lane refines: dword d of lane l at [d * 64 + l] (natural order, two coefficients per dword)
+    // the AC table of the lane's current scan as an 8-bit lookup of its own: progressive files carry tables optimised per scan, so a chunk has
+    // thousands of distinct ones and they stay in global memory -- a probe there is ~1 us on the critical path of every symbol
+    __shared__ uint16_t s_look8[256 * 64];
     for (int t = threadIdx.x; t < 80; t += 64) zz[t] = c_zigzag[t];
     if (LDS_TABLES > 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(g_luts);
@@ -605,6 +622,9 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
     uint32_t bad = 0;
     for (uint32_t sci = 0; sci < im->pscan_count && !bad; sci++) {
         const PScan P = pscans[im->pscan_first + sci];
+#ifdef RPH_PROG_TIMING
+        const uint64_t t_scan = wall_clock64();
+#endif
         BitR b;
         b.init(streams + im->stream_base + P.off, P.len);
         const uint32_t al = P.al;
@@ -664,6 +684,13 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
             const uint64_t comp_base = img_fb + c->first_block;
             const rphj::DeviceLut *A = luts + P.ac;
             const uint32_t ss = P.ss, se = P.se;
+            for (uint32_t i0 = 0; i0 < 256; i0 += 16) {
+                uint16_t e[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) e[j] = A->look[(i0 + j) << 2];
+#pragma unroll
+                for (int j = 0; j < 16; j++) s_look8[(i0 + j) * 64 + lane] = (e[j] >> 8) <= 8 ? e[j] : (uint16_t)0;
+            }
             auto block_at = [&](uint32_t bl) -> uint64_t { return (comp_base + (uint64_t)(bl / MX) * BW + bl % MX) * 64; };
             if (P.ah == 0) {
                 // first pass over the band: one symbol per step
@@ -672,7 +699,7 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                 const uint64_t max_it = (uint64_t)total * 65 + 8;
                 for (uint64_t it = 0; bl < total && it < max_it; it++) {
                     b.fill();
-                    const uint32_t rs = b.symbol(A);
+                    const uint32_t rs = b.symbol8(s_look8, lane, A);
                     if (rs > 255) {
                         bad = 1;
                         break;
@@ -709,11 +736,14 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                 if (bl < total) bad = 1;
             } else {
                 // refinement of the band: mode 0 = a symbol is due, 1 = stepping over r zero-history coefficients (then placing `value`),
-                // 2 = the block lies in an end-of-band run (correction bits only)
+                // 2 = the block lies in an end-of-band run (correction bits only).  nzb = the band's coefficients with nonzero history (bit k =
+                // zigzag position k), made when the block arrives: zero-history stretches are stepped over with bit arithmetic, so one step of
+                // the loop is one symbol, one correction bit or one placement.
                 const int p1 = 1 << al, m1 = -(1 << al);
+                const uint64_t band = ((se >= 63 ? 0ull : (1ull << (se + 1))) - 1ull) & ~((1ull << ss) - 1ull);
                 uint32_t bl = 0, k = ss, mode = 0, eobrun = 0;
                 int r = 0, value = 0;
-                uint64_t base = 0;
+                uint64_t base = 0, nzb = 0;
                 uint4 pf[8];
                 auto fetch = [&](uint32_t blk) {
                     const uint4 *src = reinterpret_cast<const uint4 *>(coef + block_at(blk));
@@ -722,13 +752,22 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                 };
                 auto enter = [&](uint32_t blk) {  // the prefetched block becomes the current one; the next is requested
                     base = block_at(blk);
+                    uint32_t w[32];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        s_blk[(4 * j + 0) * 64 + lane] = pf[j].x;
-                        s_blk[(4 * j + 1) * 64 + lane] = pf[j].y;
-                        s_blk[(4 * j + 2) * 64 + lane] = pf[j].z;
-                        s_blk[(4 * j + 3) * 64 + lane] = pf[j].w;
+                    for (int j = 0; j < 8; j++) w[4 * j] = pf[j].x, w[4 * j + 1] = pf[j].y, w[4 * j + 2] = pf[j].z, w[4 * j + 3] = pf[j].w;
+#pragma unroll
+                    for (int j = 0; j < 32; j++) s_blk[j * 64 + lane] = w[j];
+                    uint32_t lo = 0, hi = 0;
+#pragma unroll
+                    for (int kk = 1; kk < 64; kk++) {
+                        const int nat = ZZC[kk];
+                        const uint32_t half = (nat & 1) ? (w[nat >> 1] >> 16) : (w[nat >> 1] & 0xFFFFu);
+                        if (kk < 32)
+                            lo |= (half != 0 ? 1u : 0u) << kk;
+                        else
+                            hi |= (half != 0 ? 1u : 0u) << (kk - 32);
                     }
+                    nzb = (((uint64_t)hi << 32) | lo) & band;
                     if (blk + 1 < total) fetch(blk + 1);
                     k = ss;
                     mode = eobrun > 0 ? 2 : 0;
@@ -737,16 +776,16 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                     const uint32_t d = s_blk[(nat >> 1) * 64 + lane];
                     return (int)(int16_t)(nat & 1 ? d >> 16 : d & 0xFFFFu);
                 };
-                if (total) {
-                    fetch(0);
-                    enter(0);
-                }
-                const uint64_t max_it = (uint64_t)total * 130 + 8;
-                for (uint64_t it = 0; bl < total && it < max_it; it++) {
+                // block by block, the lanes of the wave in step: taking a block in (LDS copy, mask) costs as much as a dozen steps, and in a
+                // loop over steps alone some lane of the wave is at a block boundary nearly every time, so every step would pay for it
+                if (total) fetch(0);
+                for (; bl < total && !bad; bl++) {
+                  enter(bl);
+                  bool block_done = false;
+                  for (int it = 0; it < 130 && !block_done; it++) {
                     b.fill();
-                    bool block_done = false;
                     if (mode == 0) {
-                        const uint32_t rs = b.symbol(A);
+                        const uint32_t rs = b.symbol8(s_look8, lane, A);
                         if (rs > 255) {
                             bad = 1;
                             break;
@@ -769,34 +808,52 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                             mode = 1;  // sixteen zero-history coefficients to step over, nothing to place
                         }
                     } else {
-                        const uint32_t nat = zz[k];
-                        const int cv = coef_at(nat);
-                        if (cv != 0) {  // nonzero history: one correction bit
-                            if (b.take(1) && (cv & p1) == 0) coef[base + nat] = (int16_t)(cv >= 0 ? cv + p1 : cv + m1);
-                            k++;
-                            if (k > se) block_done = true;
-                        } else if (mode == 2) {
-                            k++;
-                            if (k > se) block_done = true;
-                        } else if (--r < 0) {  // the run of zeros is through: this is the new coefficient's place
-                            if (value) coef[base + nat] = (int16_t)value;
-                            k++;
-                            mode = 0;
-                            if (k > se) block_done = true;
+                        // from k on: the next coefficient with history (pn), and -- mode 1 -- where the (r + 1)-th zero-history one lies
+                        const uint64_t from_k = ~0ull << k;  // k <= 63
+                        const uint64_t nz_ahead = nzb & from_k;
+                        const uint32_t pn = nz_ahead ? (uint32_t)__builtin_ctzll(nz_ahead) : 64u;
+                        bool correct = false;  // a correction bit for position pn is due
+                        if (mode == 2) {
+                            if (pn > se)
+                                block_done = true;
+                            else
+                                correct = true;
                         } else {
-                            k++;
+                            const uint64_t before_pn = pn >= 64 ? ~0ull : ((1ull << pn) - 1ull);
+                            uint64_t zeros = ~nzb & band & from_k & before_pn;  // zero-history positions in [k, pn)
+                            const int nzeros = __builtin_popcountll(zeros);
+                            if (nzeros > r) {  // the run ends before the next coefficient with history: the new value's place
+                                for (int q = 0; q < r; q++) zeros &= zeros - 1;
+                                const uint32_t at = (uint32_t)__builtin_ctzll(zeros);
+                                if (value) coef[base + zz[at]] = (int16_t)value;
+                                k = at + 1;
+                                mode = 0;
+                                if (k > se) block_done = true;
+                            } else if (pn > se) {  // the band ends inside the run
+                                block_done = true;
+                            } else {
+                                r -= nzeros;
+                                correct = true;
+                            }
+                        }
+                        if (correct) {
+                            const uint32_t nat = zz[pn];
+                            const int cv = coef_at(nat);
+                            if (b.take(1) && (cv & p1) == 0) coef[base + nat] = (int16_t)(cv >= 0 ? cv + p1 : cv + m1);
+                            k = pn + 1;
                             if (k > se) block_done = true;
                         }
                     }
-                    if (block_done) {
-                        if (eobrun > 0) eobrun--;
-                        bl++;
-                        if (bl < total) enter(bl);
-                    }
+                  }
+                  if (!block_done) bad = 1;
+                  if (eobrun > 0) eobrun--;
                 }
                 if (bl < total) bad = 1;
             }
         }
+#ifdef RPH_PROG_TIMING
+        if (slot == 0) printf("scan %u ns=%u ss=%u se=%u ah=%u al=%u len=%u: %llu us\n", sci, P.ns, P.ss, P.se, P.ah, P.al, P.len, (unsigned long long)(wall_clock64() - t_scan) / 100);
+#endif
     }
     if (bad) status[ii] = 1;
 }
