@@ -40,6 +40,7 @@ struct HImage {
     HComp comp[3];
     HScan scan[4];
     uint32_t pscan_first, pscan_count;  // progressive files: their scans in the chunk's PScan array (n_scans = 0)
+    uint32_t mask_first, pad_;          // progressive files: index of the file's first block in the chunk's mask array (two 64-bit words per block)
 };
 struct PScan {  // one scan of a progressive file (T.81 G.1): DC scans (ss == 0) may interleave components, AC scans have one
     uint32_t off, len;       // de-stuffed entropy bytes, from the image's stream_base
@@ -94,9 +95,10 @@ int rph_jpeg_launch_color(int flavour, uint32_t max_groups, uint32_t n_images, h
 // d_order: the first n_ordered items in the order the lanes take them (longest first); items n_ordered .. n_items - 1 are taken as they lie
 int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const HItem *d_items, const uint32_t *d_order, uint32_t n_ordered,
                          uint32_t n_items, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status);
-// Progressive files, one per lane: all scans of the file one after the other (d_order: indices into d_images, longest file first)
+// Progressive files, one per lane: all scans of the file one after the other (d_order: indices into d_images, longest file first).
+// d_masks: two zeroed 64-bit words per block of the progressive files (HImage::mask_first): which coefficients are nonzero, which negative.
 int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const PScan *d_pscans, const uint32_t *d_order, uint32_t n,
-                         const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status);
+                         const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, unsigned long long *d_masks, uint8_t *d_status);
 // Segment synchronisation of the files in d_files (see above): round 0, `rounds` validation rounds, the count pass and the prefix
 // kernel, which writes the files' walk items (d_items[first_item ..]) -- n_segs of them per file, or one whole-file item and empty ones
 // when the file's chain did not verify.  d_bitmap: seg_bytes + 12 bytes per segment (marks, two `out` slots, the segment -> file map).

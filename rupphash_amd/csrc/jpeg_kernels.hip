@@ -511,14 +511,15 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
 // Progressive files (T.81 G.1.2), one per lane: the scans of a file run one after the other in the lane, each over the file's whole
 // block grid -- first DC (difference coding, value << Al), DC refinement (one bit per block), first AC of a band (runs, end-of-band
 // runs over blocks), AC refinement (a correction bit for every coefficient that is already nonzero, new +-1 values in between).
-// First scans only write.  DC refinement ORs its bit in with a fire-and-forget atomic (nothing waits for the old value).  AC
-// refinement must see what the earlier scans left: the lane keeps the block it works on in LDS (fetched as eight 16-byte loads, the
-// next block already in flight in registers) and stores the coefficients it changes one by one.  One step of the loop = one symbol
-// or one coefficient position, so the lanes of a wave stay together whatever their blocks hold.
+// Nothing here ever waits for a coefficient to come back from memory.  First scans only write.  Refinement needs to know WHICH
+// coefficients of a block are nonzero and their signs, not their values: two 64-bit masks per block (zigzag position = bit) are kept
+// beside the coefficients -- first AC scans OR their placements in with fire-and-forget atomics, a refinement scan reads the 16 bytes
+// of the block it is about to enter one block ahead -- and a correction is a fire-and-forget atomic add of +-(1 << Al) to the dword the
+// coefficient lives in (the half-word can neither carry nor borrow: its bit Al is clear and its sign is the direction), DC refinement
+// an atomic OR.  A step of the refinement loop is one symbol with the correction bits that precede its coefficient, stepped over with
+// bit arithmetic on the masks.  (A corrupt stream may set bit Al twice where libjpeg would test it first: its result is unspecified
+// either way, and every access stays inside the file's own blocks.)
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr uint8_t ZZC[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
-                            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
 struct BitR {
     const uint8_t *sbase;
     uint32_t limit, q0n, woff;
@@ -597,11 +598,10 @@ struct BitR {
 template <int LDS_TABLES>
 __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const PScan *__restrict__ pscans,
                                                        const uint32_t *__restrict__ order, uint32_t n, const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts,
-                                                       int16_t *__restrict__ coef, uint8_t *__restrict__ status)
+                                                       int16_t *__restrict__ coef, unsigned long long *__restrict__ masks, uint8_t *__restrict__ status)
 {
     __shared__ uint8_t zz[80];
     __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
-    __shared__ uint32_t s_blk[32 * 64];  // the block a lane refines: dword d of lane l at [d * 64 + l] (natural order, two coefficients per dword)
     // the AC table of the lane's current scan as an 8-bit lookup of its own: progressive files carry tables optimised per scan, so a chunk has
     // thousands of distinct ones and they stay in global memory -- a probe there is ~1 us on the critical path of every symbol
     __shared__ uint16_t s_look8[256 * 64];
@@ -619,6 +619,7 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
     const uint32_t ii = order[slot];
     const HImage *im = imgs + ii;
     const uint64_t img_fb = im->first_block;
+    unsigned long long *const my_masks = masks + 2 * (size_t)im->mask_first;  // {nonzero, negative} per block of this image
     uint32_t bad = 0;
     for (uint32_t sci = 0; sci < im->pscan_count && !bad; sci++) {
         const PScan P = pscans[im->pscan_first + sci];
@@ -696,6 +697,7 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                 // first pass over the band: one symbol per step
                 uint32_t bl = 0, k = ss;
                 uint64_t base = total ? block_at(0) : 0;
+                unsigned long long nz_acc = 0, sg_acc = 0;  // placements in the current block
                 const uint64_t max_it = (uint64_t)total * 65 + 8;
                 for (uint64_t it = 0; bl < total && it < max_it; it++) {
                     b.fill();
@@ -724,10 +726,18 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                         const uint32_t raw = b.take(s);
                         const int val = raw < (1u << (s - 1)) ? (int)raw - (int)((1u << s) - 1) : (int)raw;
                         coef[base + zz[k]] = (int16_t)(val * (1 << al));
+                        nz_acc |= 1ull << k;
+                        sg_acc |= (unsigned long long)(val < 0) << k;
                         k++;
                         if (k > se) adv = 1;
                     }
                     if (adv) {
+                        if (nz_acc) {
+                            unsigned long long *m = my_masks + 2 * (size_t)(base / 64 - img_fb);
+                            atomicOr(m, nz_acc);
+                            if (sg_acc) atomicOr(m + 1, sg_acc);
+                            nz_acc = sg_acc = 0;
+                        }
                         bl = adv > total - bl ? total : bl + adv;
                         k = ss;
                         if (bl < total) base = block_at(bl);
@@ -735,118 +745,97 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                 }
                 if (bl < total) bad = 1;
             } else {
-                // refinement of the band: mode 0 = a symbol is due, 1 = stepping over r zero-history coefficients (then placing `value`),
-                // 2 = the block lies in an end-of-band run (correction bits only).  nzb = the band's coefficients with nonzero history (bit k =
-                // zigzag position k), made when the block arrives: zero-history stretches are stepped over with bit arithmetic, so one step of
-                // the loop is one symbol, one correction bit or one placement.
-                const int p1 = 1 << al, m1 = -(1 << al);
+                // refinement of the band.  Per block: nzb = the band's positions with nonzero history, sgn = their signs.  A step: a symbol
+                // (unless the block lies in an end-of-band run), then the correction bits of the coefficients with history that come before
+                // the symbol's own place -- the (r + 1)-th zero-history position from k on -- or, when there is no such place, up to the band's end.
+                const unsigned int p1 = 1u << al;
                 const uint64_t band = ((se >= 63 ? 0ull : (1ull << (se + 1))) - 1ull) & ~((1ull << ss) - 1ull);
-                uint32_t bl = 0, k = ss, mode = 0, eobrun = 0;
-                int r = 0, value = 0;
-                uint64_t base = 0, nzb = 0;
-                uint4 pf[8];
-                auto fetch = [&](uint32_t blk) {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(coef + block_at(blk));
-#pragma unroll
-                    for (int j = 0; j < 8; j++) pf[j] = src[j];
+                uint32_t bl = 0, eobrun = 0;
+                unsigned long long pf_nz = 0, pf_sg = 0;
+                auto fetch = [&](uint32_t blk) {  // (past the L1: the first scans' atomics happen in the L2)
+                    const unsigned long long *m = my_masks + 2 * (size_t)(block_at(blk) / 64 - img_fb);
+                    pf_nz = __hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pf_sg = __hip_atomic_load(m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 };
-                auto enter = [&](uint32_t blk) {  // the prefetched block becomes the current one; the next is requested
-                    base = block_at(blk);
-                    uint32_t w[32];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) w[4 * j] = pf[j].x, w[4 * j + 1] = pf[j].y, w[4 * j + 2] = pf[j].z, w[4 * j + 3] = pf[j].w;
-#pragma unroll
-                    for (int j = 0; j < 32; j++) s_blk[j * 64 + lane] = w[j];
-                    uint32_t lo = 0, hi = 0;
-#pragma unroll
-                    for (int kk = 1; kk < 64; kk++) {
-                        const int nat = ZZC[kk];
-                        const uint32_t half = (nat & 1) ? (w[nat >> 1] >> 16) : (w[nat >> 1] & 0xFFFFu);
-                        if (kk < 32)
-                            lo |= (half != 0 ? 1u : 0u) << kk;
-                        else
-                            hi |= (half != 0 ? 1u : 0u) << (kk - 32);
-                    }
-                    nzb = (((uint64_t)hi << 32) | lo) & band;
-                    if (blk + 1 < total) fetch(blk + 1);
-                    k = ss;
-                    mode = eobrun > 0 ? 2 : 0;
-                };
-                auto coef_at = [&](uint32_t nat) -> int {
-                    const uint32_t d = s_blk[(nat >> 1) * 64 + lane];
-                    return (int)(int16_t)(nat & 1 ? d >> 16 : d & 0xFFFFu);
-                };
-                // block by block, the lanes of the wave in step: taking a block in (LDS copy, mask) costs as much as a dozen steps, and in a
-                // loop over steps alone some lane of the wave is at a block boundary nearly every time, so every step would pay for it
                 if (total) fetch(0);
                 for (; bl < total && !bad; bl++) {
-                  enter(bl);
-                  bool block_done = false;
-                  for (int it = 0; it < 130 && !block_done; it++) {
-                    b.fill();
-                    if (mode == 0) {
-                        const uint32_t rs = b.symbol8(s_look8, lane, A);
-                        if (rs > 255) {
-                            bad = 1;
-                            break;
-                        }
-                        r = (int)(rs >> 4);
-                        const uint32_t s = rs & 15;
-                        value = 0;
-                        if (s) {
-                            if (s != 1) {
+                    const uint64_t base = block_at(bl);
+                    const unsigned long long nz_all = pf_nz, sgn = pf_sg;
+                    const uint64_t nzb = nz_all & band;
+                    if (bl + 1 < total) fetch(bl + 1);
+                    unsigned long long nz_new = 0, sg_new = 0;
+                    uint32_t k = ss;
+                    bool block_done = false;
+                    for (int it = 0; it < 66 && !block_done; it++) {
+                        b.fill();
+                        int r = 0, value = 0;
+                        bool place = false;  // a symbol of this block asks for a place (mode 1); else only corrections are due
+                        if (eobrun == 0) {
+                            const uint32_t rs = b.symbol8(s_look8, lane, A);
+                            if (rs > 255) {
                                 bad = 1;
                                 break;
                             }
-                            value = b.take(1) ? p1 : m1;
-                            mode = 1;
-                        } else if (r != 15) {
-                            eobrun = 1u << r;
-                            if (r) eobrun += b.take((uint32_t)r);
-                            mode = 2;
-                        } else {
-                            mode = 1;  // sixteen zero-history coefficients to step over, nothing to place
-                        }
-                    } else {
-                        // from k on: the next coefficient with history (pn), and -- mode 1 -- where the (r + 1)-th zero-history one lies
-                        const uint64_t from_k = ~0ull << k;  // k <= 63
-                        const uint64_t nz_ahead = nzb & from_k;
-                        const uint32_t pn = nz_ahead ? (uint32_t)__builtin_ctzll(nz_ahead) : 64u;
-                        bool correct = false;  // a correction bit for position pn is due
-                        if (mode == 2) {
-                            if (pn > se)
-                                block_done = true;
-                            else
-                                correct = true;
-                        } else {
-                            const uint64_t before_pn = pn >= 64 ? ~0ull : ((1ull << pn) - 1ull);
-                            uint64_t zeros = ~nzb & band & from_k & before_pn;  // zero-history positions in [k, pn)
-                            const int nzeros = __builtin_popcountll(zeros);
-                            if (nzeros > r) {  // the run ends before the next coefficient with history: the new value's place
-                                for (int q = 0; q < r; q++) zeros &= zeros - 1;
-                                const uint32_t at = (uint32_t)__builtin_ctzll(zeros);
-                                if (value) coef[base + zz[at]] = (int16_t)value;
-                                k = at + 1;
-                                mode = 0;
-                                if (k > se) block_done = true;
-                            } else if (pn > se) {  // the band ends inside the run
-                                block_done = true;
+                            r = (int)(rs >> 4);
+                            const uint32_t s = rs & 15;
+                            if (s) {
+                                if (s != 1) {
+                                    bad = 1;
+                                    break;
+                                }
+                                value = b.take(1) ? (int)p1 : -(int)p1;
+                                place = true;
+                            } else if (r != 15) {
+                                eobrun = 1u << r;
+                                if (r) eobrun += b.take((uint32_t)r);
                             } else {
-                                r -= nzeros;
-                                correct = true;
+                                place = true;  // sixteen zero-history coefficients to step over, nothing to put down
                             }
                         }
-                        if (correct) {
-                            const uint32_t nat = zz[pn];
-                            const int cv = coef_at(nat);
-                            if (b.take(1) && (cv & p1) == 0) coef[base + nat] = (int16_t)(cv >= 0 ? cv + p1 : cv + m1);
-                            k = pn + 1;
+                        const uint64_t from_k = ~0ull << k;  // k <= 63 here
+                        uint64_t todo = nzb & from_k;         // coefficients with history that take a correction bit now
+                        uint32_t at = 64;                     // the symbol's place
+                        if (place) {
+                            uint64_t zeros = ~nzb & band & from_k;
+                            if (__builtin_popcountll(zeros) > r) {
+                                for (int q = 0; q < r; q++) zeros &= zeros - 1;
+                                at = (uint32_t)__builtin_ctzll(zeros);
+                                todo &= (1ull << at) - 1ull;
+                            }
+                        }
+                        while (todo) {
+                            b.fill();
+                            const uint32_t pos = (uint32_t)__builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            if (b.take(1)) {
+                                const uint32_t nat = zz[pos];
+                                unsigned int *d = reinterpret_cast<unsigned int *>(coef + base) + (nat >> 1);
+                                const unsigned int delta = p1 << (16 * (nat & 1));
+                                if ((sgn >> pos) & 1)
+                                    atomicSub(d, delta);
+                                else
+                                    atomicAdd(d, delta);
+                            }
+                        }
+                        if (at < 64) {
+                            if (value) {
+                                coef[base + zz[at]] = (int16_t)value;
+                                nz_new |= 1ull << at;
+                                sg_new |= (unsigned long long)(value < 0) << at;
+                            }
+                            k = at + 1;
                             if (k > se) block_done = true;
+                        } else {
+                            block_done = true;  // an end-of-band run, or the band ended inside the symbol's run of zeros
                         }
                     }
-                  }
-                  if (!block_done) bad = 1;
-                  if (eobrun > 0) eobrun--;
+                    if (!block_done) bad = 1;
+                    if (eobrun > 0) eobrun--;
+                    if (nz_new) {  // (this lane is the only writer of the block's masks during a refinement scan)
+                        unsigned long long *m = my_masks + 2 * (size_t)(base / 64 - img_fb);
+                        m[0] = nz_all | nz_new;
+                        m[1] = sgn | sg_new;
+                    }
                 }
                 if (bl < total) bad = 1;
             }
@@ -1113,14 +1102,14 @@ int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HIm
 }
 
 int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const PScan *d_pscans, const uint32_t *d_order, uint32_t n,
-                         const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status)
+                         const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, unsigned long long *d_masks, uint8_t *d_status)
 {
     if (n == 0) return RPH_OK;
     const dim3 grid((n + 63) / 64);
     if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
-        hipLaunchKernelGGL(jpeg_prog_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_order, n, d_luts, n_luts, d_coef, d_status);
+        hipLaunchKernelGGL(jpeg_prog_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_order, n, d_luts, n_luts, d_coef, d_masks, d_status);
     else
-        hipLaunchKernelGGL(jpeg_prog_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_order, n, d_luts, n_luts, d_coef, d_status);
+        hipLaunchKernelGGL(jpeg_prog_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_order, n, d_luts, n_luts, d_coef, d_masks, d_status);
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }

@@ -80,6 +80,8 @@ struct Slot {
     size_t res_images = 0;
     uint8_t *d_segwork = nullptr;  // device entropy, segmented streams: states | MCU-start bitmaps | out positions
     size_t segwork_cap = 0;
+    unsigned long long *d_pmask = nullptr;  // device entropy, progressive files: {nonzero, negative} masks, two words per block
+    size_t pmask_cap = 0;
     void release()
     {
         if (stream) (void)hipStreamSynchronize(stream);
@@ -88,6 +90,7 @@ struct Slot {
         meta.release();
         res.release();
         if (d_segwork) (void)hipFree(d_segwork);
+        if (d_pmask) (void)hipFree(d_pmask);
         if (stream) (void)hipStreamDestroy(stream);
         if (done) (void)hipEventDestroy(done);
         *this = Slot();
@@ -554,12 +557,20 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     // for the pipelining, files whose lanes have long streams (photos without markers, segments switched off) into two so that the walks are
     // not paid four times.
     size_t max_len = 0;  // longest stream one lane will walk: a file, or one restart interval of it (as the frame header announces them)
+    size_t longest_plain = 0, plain_bytes = 0, plain_files = 0;  // files without restart intervals that are long enough for segments
     for (uint32_t g : idx) {
         const rphj::Frame &f = jobs[g].frame;
         const uint64_t mcus = (uint64_t)f.mcus_x * f.mcus_y, intervals = f.restart_interval ? (mcus + f.restart_interval - 1) / f.restart_interval : 1;
-        size_t lane_len = jobs[g].len / (size_t)std::max<uint64_t>(1, intervals);
-        if (!f.restart_interval && ctx->jpeg_seg_bytes && jobs[g].len >= ctx->jpeg_seg_min_bytes) lane_len = ctx->jpeg_seg_bytes;  // (segments: three short passes)
+        const size_t lane_len = jobs[g].len / (size_t)std::max<uint64_t>(1, intervals);
+        if (!f.restart_interval && !f.progressive && ctx->jpeg_seg_bytes && jobs[g].len >= ctx->jpeg_seg_min_bytes) {
+            longest_plain = std::max(longest_plain, jobs[g].len), plain_bytes += jobs[g].len, plain_files++;
+            continue;
+        }
         max_len = std::max(max_len, lane_len);
+    }
+    if (plain_files) {  // will a quarter of them be walked as segments (the chunk loop decides the same way, per chunk)?
+        const double t_whole = 0.65e-6 * (double)longest_plain * std::max(1.0, (double)plain_files / 4 / 65536.0), t_seg = (double)plain_bytes / 4 / 31e9;
+        max_len = std::max(max_len, t_seg < 0.7 * t_whole ? (size_t)ctx->jpeg_seg_bytes : longest_plain);
     }
     size_t min_chunk = (size_t)16 << 30, parts = 0.65e-6 * (double)max_len > 0.08 ? 2 : 4;
     if (const char *e = getenv("RPH_JPEG_CHUNK_GB")) min_chunk = (size_t)atoi(e) << 30;  // experiments
@@ -677,11 +688,21 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         RPH_JPEG_STAMP("lane %d: chunk %d prepared (%zu files)", b, k, m);
         // files the walk does not take (more than four scans) go back to the host decoder; they keep their place in the chunk as holes.
         // Work items: one per restart interval where a file has them, else one per file; lanes take them longest first.
+        // Segments (three decoding passes over every byte, but a lane per KB) or one lane per file (one pass, as long as the longest file)?
+        // The walk of whole files takes ~0.65 us per byte of the longest one while the chunk has fewer lanes than the device (65 536); the
+        // segment passes move ~31 GB/s of entropy bytes (5 275 photos of 366 KB: 67 ms against 236; 25 000 files of 158 KB: 129 ms against
+        // 103).  Whole-file walks also leave most of the device to the other lane's chunk, so segments must win clearly.
+        bool use_segments = ctx->jpeg_seg_bytes != 0;
+        if (use_segments && ctx->jpeg_seg_min_bytes > 0) {
+            const double t_whole = 0.65e-6 * (double)jobs[idx[first]].len * std::max(1.0, (double)m / 65536.0), t_seg = (double)file_bytes / 31e9;
+            use_segments = t_seg < 0.7 * t_whole;
+        }
         std::vector<HItem> items;
         std::vector<uint32_t> item_len;
         std::vector<SegFile> seg_files;
         std::vector<PScan> pscans;            // the scans of the chunk's progressive files
         std::vector<uint32_t> prog_order;     // the progressive files (indices into the chunk), longest first
+        uint64_t prog_blocks = 0;             // their blocks: two mask words each
         uint32_t n_segs = 0;
         items.reserve(m);
         for (size_t i = first; i < last; i++) {
@@ -690,6 +711,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             if (j.status != RPH_OK) continue;
             const uint32_t r = (uint32_t)(i - first);
             if (j.frame.progressive) {  // one lane walks all scans of the file (jpeg_prog_kernel)
+                himgs[r].mask_first = (uint32_t)prog_blocks;
+                prog_blocks += j.frame.total_blocks;
                 himgs[r].pscan_first = (uint32_t)pscans.size();
                 himgs[r].pscan_count = (uint32_t)j.plan.prog.size();
                 for (const rphj::ScanPlan &sp : j.plan.prog) {
@@ -704,7 +727,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             }
             if (j.marks.empty()) {
                 const rphj::ScanPlan &sp0 = j.plan.scan[0];
-                if (ctx->jpeg_seg_bytes && j.plan.n_scans == 1 && sp0.restart_interval == 0 && sp0.stream_len >= ctx->jpeg_seg_min_bytes && sp0.stream_len < ((uint32_t)1 << 28)) {
+                if (use_segments && j.plan.n_scans == 1 && sp0.restart_interval == 0 && sp0.stream_len >= ctx->jpeg_seg_min_bytes && sp0.stream_len < ((uint32_t)1 << 28)) {
                     // a long stream without restart markers: cut into segments that synchronise on the device (jpeg_device.h)
                     const rphj::Frame &f = j.frame;
                     SegFile sf;
@@ -759,6 +782,13 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             RPH_HIP_CHECK(hipMalloc((void **)&S.d_segwork, segwork + segwork / 4));
             S.segwork_cap = segwork + segwork / 4;
         }
+        if (prog_blocks >= ((uint64_t)1 << 32)) return RPH_ERR_CAPACITY;  // (a chunk's coefficients are capped far below: 2^32 blocks are 512 GB)
+        if (prog_blocks && S.pmask_cap < prog_blocks * 16) {
+            if (S.d_pmask) (void)hipFree(S.d_pmask);
+            S.d_pmask = nullptr, S.pmask_cap = 0;
+            RPH_HIP_CHECK(hipMalloc((void **)&S.d_pmask, prog_blocks * 16 + prog_blocks * 4));
+            S.pmask_cap = prog_blocks * 16 + prog_blocks * 4;
+        }
         ChunkDesc D;
         std::vector<size_t> subs;
         RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, false, P.recon_coef_bytes[b], S.meta.h, 0, D, subs));
@@ -801,9 +831,10 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 RPH_TRY(rph_jpeg_launch_walk(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const HItem *>(S.meta.d + off_items),
                                              reinterpret_cast<const uint32_t *>(S.meta.d + off_order), n_ordered, n_items,
                                              reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, R.status));
+            if (prog_blocks) RPH_HIP_CHECK(hipMemsetAsync(S.d_pmask, 0, prog_blocks * 16, s));
             RPH_TRY(rph_jpeg_launch_prog(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const PScan *>(S.meta.d + off_pscan),
                                          reinterpret_cast<const uint32_t *>(S.meta.d + off_porder), (uint32_t)prog_order.size(),
-                                         reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, R.status));
+                                         reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, S.d_pmask, R.status));
             lap(t_walk);
             for (size_t q = 0; q < subs.size(); q++) {
                 const size_t r0 = subs[q], r1 = q + 1 < subs.size() ? subs[q + 1] : m;
