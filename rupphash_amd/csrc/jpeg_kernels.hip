@@ -2,8 +2,10 @@
 //
 // The reference decodes "jpg" | "jpeg" files with zune-jpeg 0.5.15 into Luma8 / Rgb8 and hands the pixels to generate_pdq_features
 // (/root/reference/src/scanner.rs:473-508, :1410).  Here everything with arithmetic in it runs on the device, a batch of files per launch:
-//   jpeg_huff_kernel   the Huffman walk of sequential files, one file -- or one restart interval -- per lane (the host decodes progressive
-//                      files and small batches instead, jpeg_host.cpp): quantised coefficients written de-zigzagged into a dense buffer
+//   jpeg_huff_kernel   the Huffman walk of sequential files, one file -- or one restart interval, or one segment of a stream without
+//                      markers (jpeg_sync_kernel) -- per lane: quantised coefficients written de-zigzagged into a dense buffer
+//   jpeg_prog_kernel   the same for progressive files, one file per lane through all its scans (small batches of either kind are
+//                      decoded by the host threads instead, jpeg_host.cpp)
 //   jpeg_idct_kernel   one lane per 8x8 block: dequantise, integer IDCT (columns, rows) entirely in registers, level shift, clamp;
 //                      128 B read and 64 B written per block -- HBM-bound, no LDS
 //   jpeg_color_kernel  one lane per 8 output pixels: chroma upsampling as a pure function of the position (no intermediate
@@ -316,8 +318,8 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const uint8_t *__restri
 // divergence beyond the rare long code.  The host only copies the entropy bytes to pinned memory with the byte stuffing undone and
 // the RSTn markers dropped (jpeg_host.cpp: memchr + memcpy speed), so what crosses PCIe is the COMPRESSED file (a few tens of KB
 // instead of 0.8 MB of coefficients), and the quantised coefficients are born in HBM.  Lanes are ordered by stream length so the
-// images of a wave finish together.  Sequential (baseline) files only: a progressive file revisits every block in up to ten scans
-// and stays with the host decoder.  Latency per image is milliseconds (the walk is serial), so this is the path for large batches
+// images of a wave finish together.  This kernel takes sequential (baseline) files; a progressive file revisits every block in up to
+// ten scans and has a kernel of its own below.  Latency per image is milliseconds (the walk is serial), so this is the path for large batches
 // only (rph_jpeg_set_entropy).
 // ---------------------------------------------------------------------------------------------------------------------------
 __constant__ uint8_t c_zigzag[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,

@@ -120,7 +120,7 @@ class Engine:
         return geo[:c], qt, coef
 
     def jpeg_set_entropy(self, where):
-        """0 = Huffman streams decoded by host threads, 1 = on the device (one file per lane), 2 = automatic (default)"""
+        """0 = Huffman streams decoded by host threads, 1 = on the device, 2 = automatic (default), 3 = device for sequential files only"""
         check(self.L.rph_jpeg_set_entropy(self.ctx, int(where)), "rph_jpeg_set_entropy")
 
     def jpeg_pdq_hash_one(self, data, flavour=0, want_coeffs=True):
