@@ -215,3 +215,207 @@ def encode_baseline(rgb, sampling=((1, 2), (1, 1), (1, 1)), quality_scale=1.0, r
             write_scan([ci])
     out.extend(b"\xff\xd9")
     return bytes(out)
+
+
+# ---- a progressive (SOF2) encoder with an arbitrary scan script --------------------------------------------------------------------
+# Pillow / libjpeg only write libjpeg's default script.  The decoders' hard cases are elsewhere: bands refined in another order than they
+# were first coded, deep successive approximation, end-of-band runs that carry correction bits, sixteen zero-history coefficients stepped
+# over inside a refinement scan, codes longer than the lookup tables.  T.81 G.1.2 procedures as libjpeg's encoder arranges them (correction
+# bits are held back until the symbol they follow is out).
+
+def _quantised_blocks(rgb, sampling, quality_scale, gray):
+    rgb = np.asarray(rgb)
+    if gray:
+        h, w = rgb.shape
+        comps = [rgb.astype(np.float64)]
+        sampling = ((1, 1),)
+    else:
+        h, w, _ = rgb.shape
+        r, g, b = [rgb[..., i].astype(np.float64) for i in range(3)]
+        comps = [0.299 * r + 0.587 * g + 0.114 * b, -0.168736 * r - 0.331264 * g + 0.5 * b + 128, 0.5 * r - 0.418688 * g - 0.081312 * b + 128]
+    hmax = max(s[0] for s in sampling)
+    vmax = max(s[1] for s in sampling)
+    mcus_x = -(-w // (8 * hmax))
+    mcus_y = -(-h // (8 * vmax))
+    ql = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62, 18, 22,
+                   37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99])
+    qc = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32)
+    qts = [np.clip(np.round(q * quality_scale), 1, 255).astype(np.int64) for q in (ql, qc)]
+    blocks = []
+    for ci, (plane, (H, V)) in enumerate(zip(comps, sampling)):
+        fx, fy = hmax // H, vmax // V
+        pw, ph = mcus_x * 8 * hmax, mcus_y * 8 * vmax
+        full = np.pad(plane, ((0, ph - h), (0, pw - w)), mode="edge")
+        small = full.reshape(ph // fy, fy, pw // fx, fx).mean(axis=(1, 3))
+        q = qts[0 if ci == 0 else 1].reshape(8, 8)
+        blk = np.round(_fdct_blocks(small) / q).astype(np.int64)
+        blocks.append(blk.reshape(blk.shape[0], blk.shape[1], 64)[:, :, ZIGZAG])  # zigzag order
+    return h, w, sampling, hmax, vmax, mcus_x, mcus_y, qts, blocks
+
+
+def _table_for(used, long_codes):
+    """a Huffman table (counts[16], symbols) for the symbols in `used`: fixed-length codes (the all-ones code stays free), or -- long_codes --
+    the first eight symbols with 2..9 bits and all the others with 16 bits (codes beyond every decoder's lookup table)"""
+    used = sorted(used)
+    counts = [0] * 16
+    if long_codes and len(used) > 8:
+        for l in range(2, 10):
+            counts[l - 1] = 1
+        counts[15] = len(used) - 8
+    else:
+        length = max(1, int(np.ceil(np.log2(len(used) + 1))))
+        counts[length - 1] = len(used)
+    return counts, used
+
+
+def encode_progressive(rgb, script, sampling=((2, 2), (1, 1), (1, 1)), quality_scale=1.0, gray=False, long_codes=False):
+    """script: list of (components, Ss, Se, Ah, Al), components a tuple of indices (several only for DC scans).  Every scan gets its own
+    Huffman table (written in front of it, slot 0 / 1 alternating so that slots are redefined between scans)."""
+    h, w, sampling, hmax, vmax, mcus_x, mcus_y, qts, blocks = _quantised_blocks(rgb, sampling, quality_scale, gray)
+    ncomp = len(blocks)
+    out = bytearray(b"\xff\xd8")
+
+    def seg(marker, payload):
+        out.extend(bytes([0xFF, marker]) + (len(payload) + 2).to_bytes(2, "big") + payload)
+
+    for t, q in enumerate(qts if ncomp > 1 else qts[:1]):
+        seg(0xDB, bytes([t]) + bytes(int(v) for v in q[ZIGZAG]))
+    sof = bytes([8]) + h.to_bytes(2, "big") + w.to_bytes(2, "big") + bytes([ncomp])
+    for ci, (H, V) in enumerate(sampling):
+        sof += bytes([ci + 1, (H << 4) | V, 0 if ci == 0 else 1])
+    seg(0xC2, sof)
+
+    def units_of(cis):
+        if len(cis) == 1:  # the component's own grid (T.81 A.2.2)
+            ci = cis[0]
+            H, V = sampling[ci]
+            bw = -(-(-(-w * H // hmax)) // 8) if ncomp > 1 else -(-w // 8)
+            bh = -(-(-(-h * V // vmax)) // 8) if ncomp > 1 else -(-h // 8)
+            return [(ci, by, bx) for by in range(bh) for bx in range(bw)]
+        return [(ci, my * sampling[ci][1] + v, mx * sampling[ci][0] + hh) for my in range(mcus_y) for mx in range(mcus_x) for ci in cis
+                for v in range(sampling[ci][1]) for hh in range(sampling[ci][0])]
+
+    for scan_no, (cis, ss, se, ah, al) in enumerate(script):
+        toks = []  # ('s', component, symbol) | ('b', value, nbits)
+        if ss == 0:
+            pred = [0] * ncomp
+            for ci, by, bx in units_of(cis):
+                c0 = int(blocks[ci][by, bx, 0])
+                if ah == 0:
+                    v = c0 >> al  # arithmetic shift: the DC point transform
+                    diff = v - pred[ci]
+                    pred[ci] = v
+                    s = abs(diff).bit_length()
+                    toks.append(("s", ci, s))
+                    if s:
+                        toks.append(("b", diff if diff >= 0 else diff + (1 << s) - 1, s))
+                else:
+                    toks.append(("b", (c0 >> al) & 1, 1))
+        else:
+            ci = cis[0]
+            eobrun = 0
+            be = []  # correction bits waiting behind the end-of-band run
+
+            def flush_eobrun():
+                nonlocal eobrun, be
+                if eobrun:
+                    n = eobrun.bit_length() - 1
+                    toks.append(("s", ci, n << 4))
+                    if n:
+                        toks.append(("b", eobrun - (1 << n), n))
+                    eobrun = 0
+                for bit in be:
+                    toks.append(("b", bit, 1))
+                be = []
+
+            for _, by, bx in units_of(cis):
+                zz = blocks[ci][by, bx]
+                mag = [abs(int(v)) >> al for v in zz]  # magnitudes are shifted, not the signed values
+                if ah == 0:
+                    r = 0
+                    for k in range(ss, se + 1):
+                        t = mag[k]
+                        if t == 0:
+                            r += 1
+                            continue
+                        flush_eobrun()
+                        while r > 15:
+                            toks.append(("s", ci, 0xF0))
+                            r -= 16
+                        s = t.bit_length()
+                        toks.append(("s", ci, (r << 4) | s))
+                        toks.append(("b", t if zz[k] >= 0 else (~t) & ((1 << s) - 1), s))
+                        r = 0
+                    if r > 0:
+                        eobrun += 1
+                        if eobrun == 0x7FFF:
+                            flush_eobrun()
+                else:
+                    eob = 0
+                    for k in range(ss, se + 1):
+                        if mag[k] == 1:
+                            eob = k
+                    r = 0
+                    br = []
+                    for k in range(ss, se + 1):
+                        t = mag[k]
+                        if t == 0:
+                            r += 1
+                            continue
+                        while r > 15 and k <= eob:
+                            flush_eobrun()
+                            toks.append(("s", ci, 0xF0))
+                            r -= 16
+                            toks.extend(("b", bit, 1) for bit in br)
+                            br = []
+                        if t > 1:
+                            br.append(t & 1)
+                            continue
+                        flush_eobrun()
+                        toks.append(("s", ci, (r << 4) | 1))
+                        toks.append(("b", 0 if zz[k] < 0 else 1, 1))
+                        toks.extend(("b", bit, 1) for bit in br)
+                        br = []
+                        r = 0
+                    if r > 0 or br:
+                        eobrun += 1
+                        be.extend(br)
+                        if eobrun == 0x7FFF or len(be) > 900:
+                            flush_eobrun()
+            flush_eobrun()
+        # tables: one per component of the scan (DC first scans) or one (AC scans); none for DC refinement
+        slot = scan_no & 1
+        codes = {}
+        sos = bytes([len(cis)])
+        for n_c, ci in enumerate(cis):
+            used = {t[2] for t in toks if t[0] == "s" and t[1] == ci}
+            tsel = (slot + n_c) & 3
+            if used:
+                counts, symbols = _table_for(used, long_codes and (scan_no + ci) % 2 == 0)
+                seg(0xC4, bytes([(0x10 if ss else 0x00) | tsel]) + bytes(counts) + bytes(symbols))
+                codes[ci] = _codes(counts, symbols)
+            sos += bytes([ci + 1, (tsel << 4) if ss == 0 else tsel])
+        seg(0xDA, sos + bytes([ss, se, (ah << 4) | al]))
+        bits = _Bits()
+        for t in toks:
+            if t[0] == "s":
+                bits.put(*codes[t[1]][t[2]])
+            else:
+                bits.put(t[1], t[2])
+        bits.flush()
+        out.extend(bits.out)
+    out.extend(b"\xff\xd9")
+    return bytes(out)
+
+
+# scan scripts for encode_progressive (three components unless noted)
+SCRIPT_LIBJPEG = [((0, 1, 2), 0, 0, 0, 1), ((0,), 1, 5, 0, 2), ((2,), 1, 63, 0, 1), ((1,), 1, 63, 0, 1), ((0,), 6, 63, 0, 2), ((0,), 1, 63, 2, 1),
+                  ((0, 1, 2), 0, 0, 1, 0), ((2,), 1, 63, 1, 0), ((1,), 1, 63, 1, 0), ((0,), 1, 63, 1, 0)]
+SCRIPT_SPECTRAL_ONLY = [((0, 1, 2), 0, 0, 0, 0), ((0,), 1, 63, 0, 0), ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0)]
+SCRIPT_DEEP = [((0,), 0, 0, 0, 3), ((1,), 0, 0, 0, 2), ((2,), 0, 0, 0, 2), ((0,), 1, 2, 0, 3), ((0,), 3, 9, 0, 3), ((0,), 10, 63, 0, 3), ((0,), 1, 63, 3, 2),
+               ((0,), 0, 0, 3, 2), ((0,), 1, 63, 2, 1), ((1,), 1, 63, 0, 2), ((1,), 1, 63, 2, 1), ((0,), 0, 0, 2, 1), ((1, 2), 0, 0, 2, 1), ((2,), 1, 63, 0, 0),
+               ((0,), 1, 63, 1, 0), ((0, 1, 2), 0, 0, 1, 0), ((1,), 1, 63, 1, 0)]
+SCRIPT_REFINE_BEFORE_OTHER_BANDS = [((0, 1, 2), 0, 0, 0, 0), ((0,), 1, 8, 0, 1), ((0,), 1, 8, 1, 0), ((0,), 9, 63, 0, 2), ((1,), 1, 63, 0, 1), ((0,), 9, 63, 2, 1),
+                                    ((1,), 1, 63, 1, 0), ((2,), 1, 30, 0, 0), ((0,), 9, 63, 1, 0), ((2,), 31, 63, 0, 1), ((2,), 31, 63, 1, 0)]
+SCRIPT_MANY_BANDS = [((0, 1, 2), 0, 0, 0, 0)] + [((c,), a, min(a + 2, 63), 0, 0) for a in range(1, 64, 3) for c in (0, 1, 2)]
+SCRIPT_GRAY = [((0,), 0, 0, 0, 1), ((0,), 1, 63, 0, 2), ((0,), 1, 63, 2, 1), ((0,), 0, 0, 1, 0), ((0,), 1, 63, 1, 0)]

@@ -289,6 +289,38 @@ def test_progressive_files_walk_on_the_device(eng, oracle):
     # DCT coefficient anywhere in such a file shows)
 
 
+def test_progressive_scan_scripts_on_the_device(eng, oracle):
+    """the device walk of progressive files on what Pillow cannot write (tests/jpeg_util.encode_progressive): bands refined in another order
+    than they were first coded (the masks a refinement scan reads were last changed by atomics of an earlier scan), successive approximation
+    three bits deep, DC scans per component, twenty bands per component, per-scan tables with 16-bit codes.  The host decoder is the reference
+    (itself checked against the oracle and libjpeg-turbo on these streams in test_oracle_jpeg.py); the oracle is asked directly on a sample."""
+    import itertools
+
+    scripts = [("libjpeg", ju.SCRIPT_LIBJPEG, False), ("spectral", ju.SCRIPT_SPECTRAL_ONLY, False), ("deep", ju.SCRIPT_DEEP, False),
+               ("order", ju.SCRIPT_REFINE_BEFORE_OTHER_BANDS, False), ("many", ju.SCRIPT_MANY_BANDS, False), ("gray", ju.SCRIPT_GRAY, True)]
+    files = []
+    for (w, h), (name, script, gray), samp, (qs, lc) in itertools.product([(64, 48), (33, 47), (7, 5), (200, 136)], scripts,
+                                                                          [((2, 2), (1, 1), (1, 1)), ((1, 1), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1))],
+                                                                          [(0.3, False), (1.0, True), (4.0, False)]):
+        if gray and samp != ((2, 2), (1, 1), (1, 1)):
+            continue
+        files.append(ju.encode_progressive(np.array(ju.make_image(w, h, "L" if gray else "RGB", seed=w + h)), script, samp, qs, gray=gray, long_codes=lc))
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    files.append(ju.encode_progressive(noise, ju.SCRIPT_DEEP, ((2, 2), (1, 1), (1, 1)), 0.1, long_codes=True))   # every coefficient nonzero: long correction runs
+    files.append(ju.encode_progressive(np.full((96, 128, 3), 200, np.uint8), ju.SCRIPT_LIBJPEG, ((2, 2), (1, 1), (1, 1)), 1.0))  # flat: one end-of-band run per scan
+    eng.jpeg_set_entropy(0)
+    host = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    eng.jpeg_set_entropy(1)
+    dev = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    eng.jpeg_set_entropy(2)
+    assert not dev["status"].any() and not host["status"].any() and np.array_equal(dev["valid"], host["valid"])
+    assert np.array_equal(dev["hash"], host["hash"]) and np.array_equal(dev["coeffs"].view(np.uint32), host["coeffs"].view(np.uint32))
+    for k in range(0, len(files), 17):
+        ok, h, _, _ = _oracle_hash(oracle, oracle.jpeg_decode(files[k], 0))
+        assert bool(dev["valid"][k]) == ok and (not ok or np.array_equal(dev["hash"][k], h)), k
+
+
 def test_restart_intervals_get_a_lane_each(eng, oracle):
     """one-scan files with restart markers are walked by one lane per interval; 60 photos with an interval per MCU row are 3 000+
     lanes, so the automatic mode takes the device walk for them; hashes equal the host decoder's and the oracle's"""

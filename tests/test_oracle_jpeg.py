@@ -90,6 +90,34 @@ def test_other_layouts_decode_like_libjpeg_turbo_and_host_decoder_matches():
     assert np.array_equal(oracle.jpeg_decode(data, oracle.JPEG_LIBJPEG), ju.pillow_decode(data))
 
 
+PROGRESSIVE_SCRIPTS = [("libjpeg", ju.SCRIPT_LIBJPEG, False), ("spectral", ju.SCRIPT_SPECTRAL_ONLY, False), ("deep", ju.SCRIPT_DEEP, False),
+                       ("order", ju.SCRIPT_REFINE_BEFORE_OTHER_BANDS, False), ("many", ju.SCRIPT_MANY_BANDS, False), ("gray", ju.SCRIPT_GRAY, True)]
+
+
+def test_progressive_scan_scripts_decode_like_libjpeg_turbo_and_host_decoder_matches():
+    """tests/jpeg_util.encode_progressive writes what Pillow cannot: bands refined in another order than they were first coded, successive
+    approximation three bits deep, DC scans per component, twenty bands per component, per-scan tables with 16-bit codes.  libjpeg-turbo
+    (Pillow) decodes every one of them; the oracle must give the same pixels and the product's host decoder the oracle's coefficients."""
+    from rupphash_amd.engine import Engine
+
+    n = 0
+    for (w, h), (name, script, gray), samp, (qs, lc) in itertools.product([(64, 48), (33, 47), (7, 5), (130, 120)], PROGRESSIVE_SCRIPTS,
+                                                                          [((2, 2), (1, 1), (1, 1)), ((1, 1), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1))],
+                                                                          [(0.3, False), (1.0, True), (4.0, False)]):
+        if gray and samp != ((2, 2), (1, 1), (1, 1)):
+            continue
+        img = np.array(ju.make_image(w, h, "L" if gray else "RGB", seed=w + h))
+        data = ju.encode_progressive(img, script, samp, qs, gray=gray, long_codes=lc)
+        ref = ju.pillow_decode(data)
+        got = oracle.jpeg_decode(data, oracle.JPEG_LIBJPEG)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (w, h, name, samp, qs, lc)
+        g, q, c = Engine.jpeg_coefficients(data)
+        g2, q2, c2 = oracle.jpeg_coefficients(data)
+        assert np.array_equal(g, g2) and np.array_equal(q, q2) and np.array_equal(c, c2), (w, h, name, samp, qs, lc)
+        n += 1
+    assert n == 4 * (5 * 3 + 1) * 3
+
+
 def test_host_decoder_gives_the_oracles_coefficients():
     """jpeg_host.cpp (lookup tables, 64-bit refills, fast AC path) against the bit-by-bit oracle: same coefficients, same geometry"""
     from rupphash_amd.engine import Engine
