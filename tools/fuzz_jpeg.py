@@ -2,7 +2,8 @@
 host threads and by the device walk (one file per lane) must give the same bytes (hash, quality bit pattern, 256 coefficients), in both
 arithmetic flavours; files with random damage inside their entropy segments must never hang or fault either path (their results are
 unspecified).  Files: random sizes 1..700 px, gray and colour, 4:4:4 / 4:2:2 / 4:2:0 from Pillow (baseline and progressive, optimised
-tables, restart intervals), 4:4:0 / one scan per component / 16-bit tables from tests/jpeg_util.encode_baseline, content from smooth to
+tables, restart intervals), 4:4:0 / one scan per component / 16-bit tables from tests/jpeg_util.encode_baseline, progressive files with
+scan scripts of their own from tests/jpeg_util.encode_progressive, content from smooth to
 pure noise (long Huffman codes, ZRLs)."""
 import os
 import sys
@@ -44,6 +45,10 @@ def random_file():
         samp = [((1, 1), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1)), ((1, 2), (1, 1), (1, 1)), ((2, 2), (1, 1), (1, 1)), ((2, 1), (2, 1), (2, 1))][int(rng.integers(0, 5))]
         return ju.encode_baseline(a, samp, float(rng.choice([0.1, 0.5, 1.0, 4.0])), int(rng.choice([0, 0, 1, 3, 17])), sixteen_bit_tables=bool(rng.random() < 0.2),
                                   interleaved=bool(rng.random() < 0.6))
+    if rng.random() < 0.2 and w * h <= 40_000:  # progressive with a scan script of its own (the Python encoder is slow: small files)
+        script = [ju.SCRIPT_LIBJPEG, ju.SCRIPT_SPECTRAL_ONLY, ju.SCRIPT_DEEP, ju.SCRIPT_REFINE_BEFORE_OTHER_BANDS, ju.SCRIPT_MANY_BANDS][int(rng.integers(0, 5))]
+        samp = [((1, 1), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1)), ((2, 2), (1, 1), (1, 1))][int(rng.integers(0, 3))]
+        return ju.encode_progressive(a, script, samp, float(rng.choice([0.1, 0.5, 1.0, 4.0])), long_codes=bool(rng.random() < 0.5))
     gray = rng.random() < 0.2
     im = Image.fromarray(a).convert("L") if gray else Image.fromarray(a)
     kw = dict(quality=int(rng.choice([5, 30, 60, 85, 95, 100])), progressive=bool(rng.random() < 0.25))
