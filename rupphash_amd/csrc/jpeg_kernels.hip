@@ -564,17 +564,28 @@ struct BitR {
         nb -= (int)n;
         return v;
     }
-    // one Huffman symbol; 0x100 = not a code of this table.  look8: the lane's own 8-bit lookup in LDS ([prefix * 64 + lane]; 0 = longer code)
-    __device__ __forceinline__ uint32_t symbol8(const uint16_t *look8, uint32_t lane, const rphj::DeviceLut *L)
+    // one Huffman symbol; 0x100 = not a code of this table.  The lane's own copy of its scan's table in LDS: look8 = 8-bit lookup
+    // ([prefix * 64 + lane]; 0 = longer code), and for the longer codes the canonical arrays (maxc / dlt: [length * 64 + lane], syms:
+    // [index * 64 + lane]).  With the long codes left in global memory nearly every step of a wave paid for one: each lane meets one
+    // only every few dozen symbols, but one lane in 64 is enough.
+    __device__ __forceinline__ uint32_t symbol8(const uint16_t *look8, const int32_t *maxc, const int32_t *dlt, const uint8_t *syms, uint32_t lane)
     {
         const uint32_t e = look8[(uint32_t)(acc >> 56) * 64 + lane];
+        uint32_t len, sym;
         if (e) {
-            const uint32_t len = e >> 8;
-            acc <<= len;
-            nb -= (int)len;
-            return e & 255;
+            len = e >> 8;
+            sym = e & 255;
+        } else {
+            const int32_t win = (int32_t)(acc >> 48);
+            uint32_t l = 9;
+            while (l <= 16 && win >= maxc[l * 64 + lane]) l++;
+            if (l > 16) return 0x100;
+            len = l;
+            sym = syms[((uint32_t)((win >> (16 - l)) + dlt[l * 64 + lane]) & 255) * 64 + lane];
         }
-        return symbol(L);
+        acc <<= len;
+        nb -= (int)len;
+        return sym;
     }
     __device__ __forceinline__ uint32_t symbol(const rphj::DeviceLut *L)
     {
@@ -607,6 +618,8 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
     // the AC table of the lane's current scan as an 8-bit lookup of its own: progressive files carry tables optimised per scan, so a chunk has
     // thousands of distinct ones and they stay in global memory -- a probe there is ~1 us on the critical path of every symbol
     __shared__ uint16_t s_look8[256 * 64];
+    __shared__ int32_t s_maxc[17 * 64], s_dlt[17 * 64];
+    __shared__ uint8_t s_syms[256 * 64];
     for (int t = threadIdx.x; t < 80; t += 64) zz[t] = c_zigzag[t];
     if (LDS_TABLES > 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(g_luts);
@@ -694,6 +707,17 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
 #pragma unroll
                 for (int j = 0; j < 16; j++) s_look8[(i0 + j) * 64 + lane] = (e[j] >> 8) <= 8 ? e[j] : (uint16_t)0;
             }
+            for (uint32_t l = 9; l <= 16; l++) {
+                s_maxc[l * 64 + lane] = A->maxcode[l];
+                s_dlt[l * 64 + lane] = A->delta[l];
+            }
+            for (uint32_t i0 = 0; i0 < 256; i0 += 16) {
+                uint32_t w4[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) w4[j] = reinterpret_cast<const uint32_t *>(A->sym)[i0 / 4 + j];
+#pragma unroll
+                for (int j = 0; j < 16; j++) s_syms[(i0 + j) * 64 + lane] = (uint8_t)(w4[j >> 2] >> (8 * (j & 3)));
+            }
             auto block_at = [&](uint32_t bl) -> uint64_t { return (comp_base + (uint64_t)(bl / MX) * BW + bl % MX) * 64; };
             if (P.ah == 0) {
                 // first pass over the band: one symbol per step
@@ -703,7 +727,7 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                 const uint64_t max_it = (uint64_t)total * 65 + 8;
                 for (uint64_t it = 0; bl < total && it < max_it; it++) {
                     b.fill();
-                    const uint32_t rs = b.symbol8(s_look8, lane, A);
+                    const uint32_t rs = b.symbol8(s_look8, s_maxc, s_dlt, s_syms, lane);
                     if (rs > 255) {
                         bad = 1;
                         break;
@@ -773,7 +797,7 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                         int r = 0, value = 0;
                         bool place = false;  // a symbol of this block asks for a place (mode 1); else only corrections are due
                         if (eobrun == 0) {
-                            const uint32_t rs = b.symbol8(s_look8, lane, A);
+                            const uint32_t rs = b.symbol8(s_look8, s_maxc, s_dlt, s_syms, lane);
                             if (rs > 255) {
                                 bad = 1;
                                 break;
