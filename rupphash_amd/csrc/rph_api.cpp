@@ -315,7 +315,7 @@ int rph_hamming_set_kernel(rph_ctx *ctx, int which)
 
 int rph_pdq_set_kernel(rph_ctx *ctx, int which)
 {
-    if (!ctx || which < 0 || which > 4) return RPH_ERR_INVALID_ARG;
+    if (!ctx || which < 0 || which > 5) return RPH_ERR_INVALID_ARG;
     ctx->pdq_kernel = which;
     return RPH_OK;
 }
@@ -348,7 +348,7 @@ int rph_pdq_hash_batch_dev(rph_ctx *ctx, const void *d_px, uint32_t n, uint32_t 
     if (w > RPH_PDQ_MAX_DIM || h > RPH_PDQ_MAX_DIM)  // pre-downsample to the <= 512 px thumbnail first (pdqhash.rs:181-191)
         return rph_launch_pdq_resized(ctx, (const uint8_t *)d_px, n, w, h, channels, row_stride, image_stride, (uint8_t *)d_hash32,
                                       (float *)d_quality, (float *)d_coeffs, (uint8_t *)d_dihedral, (uint8_t *)d_valid, s);
-    if (ctx->pdq_kernel >= 1 && w == 512 && h == 512 && (channels == 3 || channels == 1) && (row_stride % 4) == 0 && (image_stride % 4) == 0 &&
+    if (ctx->pdq_kernel >= 1 && ctx->pdq_kernel != 5 && w == 512 && h == 512 && (channels == 3 || channels == 1) && (row_stride % 4) == 0 && (image_stride % 4) == 0 &&
         ((uintptr_t)d_px % 4) == 0 && row_stride <= ((size_t)1 << 22)) {  // the fused kernel uses 32-bit in-image offsets
         int rc = rph_launch_pdq_fused512(ctx, (const uint8_t *)d_px, n, row_stride, image_stride, (uint8_t *)d_hash32,
                                          (float *)d_quality, (float *)d_coeffs, (uint8_t *)d_dihedral, (uint8_t *)d_valid, s, channels);
