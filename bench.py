@@ -514,6 +514,33 @@ def jpeg_leg(eng, np, args, oracle):
             rc, coeffs, _ = oracle.pdq_features(oracle.jpeg_decode(base[k], 0))
             ok = ok and rc == 0 and bool(np.array_equal(dev["hash"][k], oracle.to_hash(coeffs)))
         out["gpu_hashes_equal_cpu_oracle_on_sample"] = ok
+    # Photo-sized and progressive files (what collections hold): the reference's own bench image (tests/golden/bench.jpg, 1280x854), 16 crops
+    # re-coded baseline 4:2:0 q90 without restart markers (streams cut into segments that synchronise on the device) and as progressive files
+    # (one lane per file through all scans); > 512 px, so the pre-downsample and the multi-pass hasher follow the decode.
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "bench.jpg")
+    if os.path.exists(golden) and n >= 20000:
+        im = Image.open(golden)
+        eng.jpeg_set_entropy(1)
+        for label, kw in (("photos_baseline", {}), ("photos_progressive", {"progressive": True})):
+            variants = []
+            for k in range(16):
+                buf = io.BytesIO()
+                im.crop((k, k // 2, 1280 - (15 - k), 854 - (7 - k // 2))).save(buf, "JPEG", quality=90, subsampling=2, **kw)
+                variants.append(buf.getvalue())
+            m_ph = 8000
+            ph = eng.jpeg_file_list([variants[k % 16] for k in range(m_ph)])
+            eng.jpeg_pdq_hash_batch(ph, threads=cores)
+            t0 = time.perf_counter()
+            got = eng.jpeg_pdq_hash_batch(ph, threads=cores)
+            dt = time.perf_counter() - t0
+            good = bool(got["valid"].all())
+            if oracle is not None:
+                rc, coeffs, _ = oracle.pdq_features(oracle.jpeg_decode(variants[3], 0))
+                good = good and rc == 0 and bool(np.array_equal(got["hash"][3], oracle.to_hash(coeffs)))
+            ok = ok and good
+            out[label] = {"files_per_s": m_ph / dt, "files": m_ph, "mean_file_bytes": sum(len(v) for v in variants) / 16, "geometry": "1265x850 (crops of tests/golden/bench.jpg)",
+                          "jpeg_MB_per_s": sum(len(variants[k % 16]) for k in range(m_ph)) / dt / 1e6, "hash_equals_cpu_oracle_on_sample": good}
+        eng.jpeg_set_entropy(2)
     out["valid"] = ok
     if not ok:
         out["problem"] = "device-entropy, host-entropy and oracle hashes differ"

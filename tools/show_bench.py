@@ -19,6 +19,7 @@ for path in sys.argv[1:]:
     if "jpeg" in d and "device_entropy" in d["jpeg"]:
         j = d["jpeg"]
         parts.append(f"jpeg {j['device_entropy']['files_per_s'] / 1e3:.0f} k files/s device entropy, {j['host_entropy']['files_per_s'] / 1e3:.1f} k host entropy, "
-                     f"libjpeg-turbo 1 thread {j['cpu_baseline']['value'] / 1e3:.2f} k")
+                     f"libjpeg-turbo 1 thread {j['cpu_baseline']['value'] / 1e3:.2f} k"
+                     + (f", photos {j['photos_baseline']['files_per_s'] / 1e3:.1f} k / progressive {j['photos_progressive']['files_per_s'] / 1e3:.1f} k files/s" if "photos_baseline" in j else ""))
     parts.append(f"valid={d.get('valid')}")
     print(" | ".join(parts))
