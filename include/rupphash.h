@@ -327,8 +327,9 @@ int rph_coeff_record_decode(const uint8_t *rec, size_t len, float *coeffs_out, s
 /* =====================================================================
  * JPEG decode feeding the hasher.  Replaces the "jpg" | "jpeg" arm of load_image_fast
  * (reference: src/scanner.rs:461-508: zune-jpeg 0.5.15 -> Luma8 for one component, Rgb8 for three) followed by
- * generate_pdq_features (scanner.rs:1410).  The host undoes the entropy coding (one image per host thread, like the
- * reference's rayon workers, scanner.rs:1202); dequantisation, IDCT, chroma upsampling, colour conversion, luma and
+ * generate_pdq_features (scanner.rs:1410).  The entropy coding is undone on the device too when a call brings enough
+ * files (rph_jpeg_set_entropy; the host then only strips the byte stuffing), else by the host threads, one image each like
+ * the reference's rayon workers (scanner.rs:1202); dequantisation, IDCT, chroma upsampling, colour conversion, luma and
  * the hash run on the device, a batch of files per launch, and only the hashes come back.
  * Supported: baseline / extended sequential / progressive Huffman JPEG, 8 bit, 1 or 3 components, luma sampling
  * 1x1, 2x1, 1x2, 2x2 with 1x1 chroma, restart intervals.  Anything else (CMYK, arithmetic coding, 12 bit, lossless)
@@ -367,7 +368,7 @@ int rph_jpeg_pdq_hash_batch(rph_ctx *ctx, const uint8_t *const *data, const size
 int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int flavour, uint8_t *hash32_out, float *quality_out, float *coeffs_out,
                           uint8_t *valid_out);
 
-/* Where rph_jpeg_pdq_hash_batch decodes the Huffman streams of sequential (baseline) files:
+/* Where rph_jpeg_pdq_hash_batch decodes the Huffman streams:
  *   RPH_JPEG_ENTROPY_HOST (0)    n_threads host threads, one file each; the coefficients cross PCIe (0.8 MB per 512x512 file);
  *   RPH_JPEG_ENTROPY_DEVICE (1)  on the device, one file per lane: the host only copies the entropy bytes (stuffing undone) and the
  *                                compressed bytes cross PCIe; the walk of one file is serial (milliseconds), so this pays from
@@ -385,7 +386,8 @@ int rph_jpeg_set_entropy(rph_ctx *ctx, int where);
 /* Tuning of the device walk for streams WITHOUT restart markers: from min_stream_bytes of entropy-coded data (default 65536) a
  * stream is cut into segments of segment_bytes (default 1024; a multiple of 4 in 64 .. 65536; 0 = never) that find their
  * entry points on the device (Huffman streams re-synchronise; the chain of entries is verified, a file that does not verify is
- * walked by one lane) and are then walked side by side.  Same results whatever the setting. */
+ * walked by one lane) and are then walked side by side -- unless, for a chunk of the call, one lane per file is estimated to be
+ * quicker (many shorter files).  min_stream_bytes = 0 forces segments for every such file (tests).  Same results whatever the setting. */
 int rph_jpeg_set_segments(rph_ctx *ctx, uint32_t min_stream_bytes, uint32_t segment_bytes);
 /* The JPEG path keeps its staging and device buffers in the context between calls (for a large call up to half of the free device
  * memory for the coefficients of the files in flight); this returns them.  The next call allocates again. */
