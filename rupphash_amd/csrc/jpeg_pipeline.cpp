@@ -886,31 +886,40 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
             if (j.status == RPH_OK && j.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) j.status = RPH_ERR_UNSUPPORTED;
         });
     RPH_JPEG_STAMP("frames parsed");
-    // which files walk their Huffman streams on the device: sequential ones, when the batch is large enough to fill lanes
+    // Which files walk their Huffman streams on the device?  In automatic mode, those for which it is estimated to pay:
+    //  * sequential files when the call has lanes to fill -- one per file, or one per restart interval where the frame header announces
+    //    them (a few dozen photos with restart markers are thousands of short streams); a long stream without markers is cut into
+    //    segments, whose passes cost ~10 ms of launches before they scale: counted as a lane per 8 KB, so that ~50 photos qualify (16 host
+    //    threads decode 130 MB/s each);
+    //  * progressive files, one lane each whatever their size, when the host threads (~41 MB/s each) would need longer for all of them
+    //    than a lane needs for the longest (~0.95 us per byte).
     std::vector<uint32_t> host_idx, dev_idx;
+    const bool may_device = ctx->jpeg_entropy != 0 && out.want_hash && !prepared;
+    uint64_t lanes = 0, prog_bytes = 0, prog_longest = 0;
     for (uint32_t i = 0; i < n; i++) {
         const Job &j = jobs[i];
-        if (j.status == RPH_OK && (!j.frame.progressive || ctx->jpeg_progressive_on_device) && ctx->jpeg_entropy != 0 && out.want_hash && !prepared)
+        if (j.status != RPH_OK || !may_device) continue;
+        const rphj::Frame &f = j.frame;
+        if (f.progressive) {
+            prog_bytes += j.len;
+            prog_longest = std::max<uint64_t>(prog_longest, j.len);
+        } else if (f.restart_interval) {
+            lanes += ((uint64_t)f.mcus_x * f.mcus_y + f.restart_interval - 1) / f.restart_interval;
+        } else if (ctx->jpeg_seg_bytes && j.len >= ctx->jpeg_seg_min_bytes) {
+            lanes += std::max<uint64_t>(1, j.len / 8192);
+        } else {
+            lanes += 1;
+        }
+    }
+    const bool seq_on_device = may_device && (ctx->jpeg_entropy == 1 || lanes >= DEVICE_ENTROPY_MIN_FILES);
+    const bool prog_on_device = may_device && ctx->jpeg_progressive_on_device &&
+                                (ctx->jpeg_entropy == 1 || (double)prog_bytes / ((double)threads * 41e6) > 0.95e-6 * (double)prog_longest);
+    for (uint32_t i = 0; i < n; i++) {
+        const Job &j = jobs[i];
+        if (j.status == RPH_OK && (j.frame.progressive ? prog_on_device : seq_on_device))
             dev_idx.push_back(i);
         else
             host_idx.push_back(i);
-    }
-    // automatic mode: the device walk pays when it has lanes to fill -- one per file, or one per restart interval where the frame
-    // header announces them (a few dozen photos with restart markers are thousands of short streams)
-    uint64_t lanes = 0;
-    for (uint32_t i : dev_idx) {
-        const rphj::Frame &f = jobs[i].frame;
-        if (f.restart_interval)
-            lanes += ((uint64_t)f.mcus_x * f.mcus_y + f.restart_interval - 1) / f.restart_interval;
-        else if (ctx->jpeg_seg_bytes && jobs[i].len >= ctx->jpeg_seg_min_bytes)
-            lanes += jobs[i].len / ctx->jpeg_seg_bytes;  // a long stream without markers is cut into segments
-        else
-            lanes += 1;
-    }
-    if (ctx->jpeg_entropy == 2 && lanes < DEVICE_ENTROPY_MIN_FILES) {
-        host_idx.clear();
-        for (uint32_t i = 0; i < n; i++) host_idx.push_back(i);
-        dev_idx.clear();
     }
     if (!dev_idx.empty()) {
         std::vector<uint32_t> leftover;
