@@ -149,6 +149,38 @@ def test_pdq_with_predownsample_matches_oracle(eng, oracle, w, h, ch, which):
         assert np.array_equal(out["dihedral"][k], oracle.dihedral_hashes(coeffs))
 
 
+ODD_LARGE = [(5000, 3000, 3), (8191, 17, 1), (513, 513, 4), (6000, 7, 3), (7, 6000, 1), (2049, 1025, 3), (30000, 20, 3), (20, 30000, 1), (9000, 6000, 1), (1537, 1024, 3),
+             (3073, 2049, 1), (4097, 513, 4)]
+
+
+@pytest.mark.parametrize("w,h,ch", ODD_LARGE)
+def test_predownsample_odd_and_very_large_geometries(eng, oracle, w, h, ch):
+    """the fused resize kernel's corners: windows of 3 / 5 / 7 and beyond (scale > 6: the general form), staged rows of one to eight
+    256-byte pieces and beyond (two-pass fallback), tiles cut by the right and bottom edges, thumbnails one pixel wide or high, sources of
+    tens of megapixels.  Default kernels == plain two-pass kernels, and the oracle where it is quick enough"""
+    rng = np.random.default_rng(w + 3 * h + ch)
+    shape = (2, h, w) if ch == 1 else (2, h, w, ch)
+    imgs = rng.integers(0, 256, shape, dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    grad = ((xx * 200) // max(w - 1, 1) + (yy * 55) // max(h - 1, 1)).astype(np.uint8)
+    if ch == 1:
+        imgs[0] = grad
+    else:
+        imgs[0, ..., 1] = grad
+    outs = []
+    for which in (0, 4):
+        eng.set_pdq_kernel(which)
+        outs.append(eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True))
+    eng.set_pdq_kernel(4)
+    assert np.array_equal(outs[0]["valid"], outs[1]["valid"]) and outs[1]["valid"].all()
+    assert np.array_equal(outs[0]["hash"], outs[1]["hash"]) and np.array_equal(outs[0]["dihedral"], outs[1]["dihedral"])
+    assert np.array_equal(outs[0]["coeffs"].view(np.uint32), outs[1]["coeffs"].view(np.uint32))
+    assert np.array_equal(outs[0]["quality"].view(np.uint32), outs[1]["quality"].view(np.uint32))
+    if w * h <= 16_000_000:
+        rc, coeffs, q = oracle.pdq_features(imgs[1])
+        assert rc == 0 and np.array_equal(bits(outs[1]["coeffs"][1]), bits(coeffs)) and np.array_equal(outs[1]["hash"][1], oracle.to_hash(coeffs))
+
+
 def lcg_features(seed):
     state = np.uint32(seed)
     out = np.zeros(256, np.float32)
