@@ -309,6 +309,8 @@ def test_progressive_scan_scripts_on_the_device(eng, oracle):
     noise = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
     files.append(ju.encode_progressive(noise, ju.SCRIPT_DEEP, ((2, 2), (1, 1), (1, 1)), 0.1, long_codes=True))   # every coefficient nonzero: long correction runs
     files.append(ju.encode_progressive(np.full((96, 128, 3), 200, np.uint8), ju.SCRIPT_LIBJPEG, ((2, 2), (1, 1), (1, 1)), 1.0))  # flat: one end-of-band run per scan
+    one_by_one = [((0, 1, 2), 0, 0, 0, 0)] + [((c,), k, k, 0, 0) for k in range(1, 64) for c in (0, 1, 2)]  # 190 scans: more than the device plan holds -> host threads
+    files.append(ju.encode_progressive(np.array(ju.make_image(40, 24, seed=77)), one_by_one, ((1, 1), (1, 1), (1, 1)), 0.5))
     eng.jpeg_set_entropy(0)
     host = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
     eng.jpeg_set_entropy(1)
