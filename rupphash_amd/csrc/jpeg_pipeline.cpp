@@ -111,20 +111,20 @@ struct Slot {
         return RPH_OK;
     }
 };
+constexpr int JPEG_LANES = 3;  // chunks in flight in the device-entropy pipeline (the host-entropy pipeline uses the first two)
 struct JpegPipe {
-    Slot slot[2];
+    Slot slot[JPEG_LANES];
     // reconstruction buffers (sample planes, packed pixels) shared by the slots' sub-batches: used in stream order, one sub-batch at a
     // time per stream; each slot owns one pair
-    uint8_t *d_planes[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
-    size_t recon_coef_bytes[2] = {0, 0};
+    uint8_t *d_planes[JPEG_LANES] = {}, *d_out[JPEG_LANES] = {};
+    size_t recon_coef_bytes[JPEG_LANES] = {};
     // device entropy: the chunk's coefficient buffer (one: chunks run back to back on one stream)
     int16_t *d_coef = nullptr;
     size_t d_coef_bytes = 0;
     void release()
     {
-        slot[0].release();
-        slot[1].release();
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < JPEG_LANES; b++) {
+            slot[b].release();
             if (d_planes[b]) (void)hipFree(d_planes[b]);
             if (d_out[b]) (void)hipFree(d_out[b]);
             d_planes[b] = d_out[b] = nullptr;
@@ -548,8 +548,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     size_t free_b = 0, total_b = 0;
     RPH_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     const size_t budget = std::max<size_t>((size_t)1 << 30, std::min<size_t>((free_b + P.d_coef_bytes) / 2, (size_t)96 << 30));
-    // Two lanes of resources (stream, staging, half of the coefficient buffer, reconstruction buffers), chunks alternate between
-    // them: the host prepares chunk k + 1 and its bytes cross PCIe while chunk k is on the device, and the latency-bound walk of one
+    // Up to JPEG_LANES lanes of resources (stream, staging, a share of the coefficient buffer, reconstruction buffers), chunks take them in
+    // turn: the host prepares chunk k + 1 and its bytes cross PCIe while chunk k is on the device, and the latency-bound walk of one
     // chunk runs beside the bandwidth-bound reconstruction of the other.  A call is cut into about four chunks when it is large
     // enough for each to still fill the device's lanes (16 GB of coefficients = 20 000 images of 512x512); a smaller call is one chunk.
     // The walk of a chunk takes as long as its longest file (~0.65 us per entropy byte: 21 ms for 29 KB files, 236 ms for 366 KB photos)
@@ -577,7 +577,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     if (const char *e = getenv("RPH_JPEG_PARTS")) parts = (size_t)atoi(e);
     const size_t chunk_target = std::min(need, std::max(need / parts + 128, min_chunk));
     const bool single = need <= chunk_target && need <= budget;
-    const size_t want = single ? need : std::min(budget, 2 * chunk_target);
+    const int lanes = single ? 1 : (int)std::min<size_t>(JPEG_LANES, (need + chunk_target - 1) / chunk_target);  // chunks in flight
+    const size_t want = single ? need : std::min(budget, (size_t)lanes * chunk_target);
     if (P.d_coef_bytes < want) {
         RPH_HIP_CHECK(hipDeviceSynchronize());
         if (P.d_coef) (void)hipFree(P.d_coef);
@@ -586,12 +587,12 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         RPH_HIP_CHECK(hipMalloc((void **)&P.d_coef, want));
         P.d_coef_bytes = want;
     }
-    const size_t region = (single ? P.d_coef_bytes : P.d_coef_bytes / 2) / 128 * 128;
+    const size_t region = (P.d_coef_bytes / (size_t)lanes) / 128 * 128;
     const size_t chunk_bytes = std::min(region, chunk_target);
     struct Pending {
         bool active = false;
         size_t first = 0, last = 0;
-    } pend[2];
+    } pend[JPEG_LANES];
     auto finish = [&](int b) -> int {
         if (!pend[b].active) return RPH_OK;
         RPH_JPEG_STAMP("lane %d: waiting for its chunk", b);
@@ -603,14 +604,12 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         pend[b].active = false;
         return RPH_OK;
     };
-    RPH_TRY(P.slot[0].ready());
-    RPH_TRY(P.slot[1].ready());
+    for (int b = 0; b < lanes; b++) RPH_TRY(P.slot[b].ready());
     {
         size_t max_img = 0;  // a sub-batch holds at least one image
         for (uint32_t g : idx) max_img = std::max(max_img, (size_t)jobs[g].frame.total_blocks * 128);
         const size_t recon = std::max(std::min(SUB_COEF_BYTES, std::max(std::min(want, chunk_bytes), (size_t)64 << 20)), max_img);
-        RPH_TRY(P.reserve_recon(0, recon, P.slot[0].stream));
-        if (need > chunk_bytes) RPH_TRY(P.reserve_recon(1, recon, P.slot[1].stream));
+        for (int b = 0; b < lanes; b++) RPH_TRY(P.reserve_recon(b, recon, P.slot[b].stream));
     }
     const size_t n = idx.size();
     int k = 0;
@@ -630,11 +629,11 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             k--;
             continue;
         }
-        const int b = k & 1;
-        RPH_TRY(finish(b));  // the lane is free again once its previous chunk (two chunks back) has delivered its results
+        const int b = k % lanes;
+        RPH_TRY(finish(b));  // the lane is free again once its previous chunk (`lanes` chunks back) has delivered its results
         Slot &S = P.slot[b];
         hipStream_t s = S.stream;
-        int16_t *d_coef = P.d_coef + (single ? 0 : (size_t)b * (region / 2));
+        int16_t *d_coef = P.d_coef + (size_t)b * (region / 2);  // (int16 elements: region bytes per lane)
         const size_t m = last - first;
         RPH_TRY(S.reserve_res(m));
         RPH_TRY(S.stream_bytes.reserve(file_bytes + 64));
@@ -853,8 +852,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         pend[b].last = last;
         first = last;
     }
-    RPH_TRY(finish(k & 1));
-    RPH_TRY(finish((k + 1) & 1));
+    for (int t = 0; t < lanes; t++) RPH_TRY(finish((k + t) % lanes));  // oldest first
     // files handed to the host decoder start over there
     for (uint32_t g : leftover) jobs[g].status = RPH_OK;
     return RPH_OK;
