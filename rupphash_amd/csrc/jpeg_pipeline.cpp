@@ -85,6 +85,7 @@ struct Slot {
     void release()
     {
         if (stream) (void)hipStreamSynchronize(stream);
+        if (res.d == res.h) res.d = nullptr;  // (one allocation: see reserve_res)
         coef.release();
         stream_bytes.release();
         meta.release();
@@ -106,7 +107,11 @@ struct Slot {
         if (res_images >= images) return RPH_OK;
         RPH_HIP_CHECK(hipStreamSynchronize(stream));
         images += images / 4;
-        RPH_TRY(res.reserve(images * RES_BYTES));
+        // pinned host memory the kernels write into directly (32 B .. 1.3 KB per image cross PCIe as they are produced): a copy back at the
+        // end of a chunk queued behind the other lanes' kernels and held the lane up for tens of milliseconds
+        if (res.d == res.h) res.d = nullptr;
+        RPH_TRY(res.reserve(images * RES_BYTES, true, false));
+        res.d = res.h;
         res_images = images;
         return RPH_OK;
     }
@@ -413,17 +418,21 @@ int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, Jobs &jobs, 
 // The results of a chunk are fetched only when the chunk is known to be finished.  Enqueued behind the chunk's kernels instead, the
 // transfer would sit in the copy engine's queue waiting for them, and the next chunk's upload -- same engine, another stream --
 // would wait behind it (measured: uploads did not overlap the other lane's kernels at all).
+// the first m entries of the slot's result arrays cleared by the host (the lane is idle: its previous chunk has delivered)
+void zero_results(Slot &S, size_t m, const Outputs &out)
+{
+    ResView H(S.res.h, S.res_images);
+    memset(H.hash, 0, m * 32);
+    memset(H.quality, 0, m * 4);
+    if (out.coeffs) memset(H.coeffs, 0, m * 1024);
+    if (out.dihedral) memset(H.dihedral, 0, m * 256);
+    memset(H.valid, 0, m);
+    memset(H.status, 0, m);
+}
+
 int fetch_results(Slot &S, size_t m, const Outputs &out, bool entropy_status)
 {
-    ResView H(S.res.h, S.res_images), D(S.res.d, S.res_images);
-    if (out.want_hash) {
-        RPH_HIP_CHECK(hipMemcpy(H.hash, D.hash, m * 32, hipMemcpyDeviceToHost));
-        if (out.quality) RPH_HIP_CHECK(hipMemcpy(H.quality, D.quality, m * 4, hipMemcpyDeviceToHost));
-        if (out.coeffs) RPH_HIP_CHECK(hipMemcpy(H.coeffs, D.coeffs, m * 1024, hipMemcpyDeviceToHost));
-        if (out.dihedral) RPH_HIP_CHECK(hipMemcpy(H.dihedral, D.dihedral, m * 256, hipMemcpyDeviceToHost));
-        RPH_HIP_CHECK(hipMemcpy(H.valid, D.valid, m, hipMemcpyDeviceToHost));
-    }
-    if (entropy_status) RPH_HIP_CHECK(hipMemcpy(H.status, D.status, m, hipMemcpyDeviceToHost));
+    (void)S, (void)m, (void)out, (void)entropy_status;  // the kernels wrote into the slot's pinned results buffer; the caller has waited for them
     return RPH_OK;
 }
 
@@ -507,7 +516,7 @@ int run_host_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, const std::vector<ui
         std::vector<size_t> subs;
         RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, out.pixels != nullptr, SIZE_MAX / 256, S.meta.h, 0, D, subs));
         hipStream_t s = S.stream;
-        RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
+        zero_results(S, m, out);
         if (D.n_images) {
             if (predecoded) {  // every caller decoded into its own pinned buffer: the copy engine takes the coefficients from there
                 for (size_t i = first; i < last; i++) {
@@ -811,7 +820,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             }
         };
         ResView R(S.res.d, S.res_images);
-        RPH_HIP_CHECK(hipMemsetAsync(S.res.d, 0, S.res_images * RES_BYTES, s));
+        zero_results(S, m, out);
         if (n_items || !prog_order.empty()) {
             RPH_HIP_CHECK(hipMemcpyAsync(S.stream_bytes.d, S.stream_bytes.h, file_bytes + 64, hipMemcpyHostToDevice, s));
             RPH_HIP_CHECK(hipMemcpyAsync(S.meta.d, S.meta.h, upload_bytes, hipMemcpyHostToDevice, s));
