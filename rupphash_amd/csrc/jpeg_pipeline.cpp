@@ -169,24 +169,67 @@ struct TableStore {
     std::vector<rphj::DeviceLut> luts;
     std::vector<rphj::TableSpec> specs;
     std::unordered_multimap<uint64_t, uint32_t> by_hash;
+    uint64_t serial = next_serial();  // tells a thread's cache of ids that it belongs to another store
+    static uint64_t next_serial()
+    {
+        static std::atomic<uint64_t> n{1};
+        return n.fetch_add(1);
+    }
+    static bool same(const rphj::TableSpec &a, const rphj::TableSpec &b)
+    {
+        return a.total == b.total && memcmp(a.counts + 1, b.counts + 1, 16) == 0 && memcmp(a.symbols, b.symbols, a.total) == 0;
+    }
+    uint32_t find_locked(uint64_t h, const rphj::TableSpec &t) const
+    {
+        auto range = by_hash.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it)
+            if (same(specs[it->second], t)) return it->second;
+        return UINT32_MAX;
+    }
+    // Every file of a call asks for its four tables, from sixteen threads: a collection has a handful of distinct tables, so each thread
+    // remembers the last few it was given (no lock at all for them); a table nobody has seen is built OUTSIDE the lock (progressive files
+    // carry tables of their own, ten per file: building them under the lock serialised the whole preparation).
     static uint32_t intern(void *self, const rphj::TableSpec &t)
     {
         TableStore &T = *static_cast<TableStore *>(self);
         uint64_t h = 1469598103934665603ULL;
         for (int q = 1; q <= 16; q++) h = (h ^ t.counts[q]) * 1099511628211ULL;
         for (int q = 0; q < t.total; q++) h = (h ^ t.symbols[q]) * 1099511628211ULL;
-        std::lock_guard<std::mutex> lock(T.mu);
-        auto range = T.by_hash.equal_range(h);
-        for (auto it = range.first; it != range.second; ++it) {
-            const rphj::TableSpec &o = T.specs[it->second];
-            if (o.total == t.total && memcmp(o.counts + 1, t.counts + 1, 16) == 0 && memcmp(o.symbols, t.symbols, t.total) == 0) return it->second;
+        struct Recent {
+            uint64_t serial = 0, hash[8];
+            uint32_t id[8];
+            rphj::TableSpec spec[8];
+            int n = 0, next = 0;
+        };
+        static thread_local Recent recent;
+        if (recent.serial != T.serial) {
+            recent.serial = T.serial;
+            recent.n = recent.next = 0;
         }
-        rphj::DeviceLut L;
-        if (rphj::build_device_lut(t, L) != RPH_OK) return UINT32_MAX;
-        T.luts.push_back(L);
-        T.specs.push_back(t);
-        T.by_hash.emplace(h, (uint32_t)T.luts.size() - 1);
-        return (uint32_t)T.luts.size() - 1;
+        for (int i = 0; i < recent.n; i++)
+            if (recent.hash[i] == h && same(recent.spec[i], t)) return recent.id[i];
+        uint32_t id;
+        {
+            std::lock_guard<std::mutex> lock(T.mu);
+            id = T.find_locked(h, t);
+        }
+        if (id == UINT32_MAX) {
+            rphj::DeviceLut L;
+            if (rphj::build_device_lut(t, L) != RPH_OK) return UINT32_MAX;
+            std::lock_guard<std::mutex> lock(T.mu);
+            id = T.find_locked(h, t);  // (another thread may have been quicker)
+            if (id == UINT32_MAX) {
+                T.luts.push_back(L);
+                T.specs.push_back(t);
+                id = (uint32_t)T.luts.size() - 1;
+                T.by_hash.emplace(h, id);
+            }
+        }
+        const int slot = recent.n < 8 ? recent.n++ : (recent.next = (recent.next + 1) & 7);
+        recent.hash[slot] = h;
+        recent.id[slot] = id;
+        recent.spec[slot] = t;
+        return id;
     }
 };
 
