@@ -178,6 +178,25 @@ __device__ __forceinline__ void tail_row(TailAcc &a, float brow, int k, int lane
     a.prev = brow;
 }
 
+// The same for a wave whose lanes feed their columns at different times (pdq_stream.hip: groups of kept columns finish a band one after
+// the other): the horizontal gradient of the pair (j - 1, j) is taken by lane j from its LEFT neighbour's value -- the same pairs, the
+// same expression (a - b) with a the left value, so the same integers.
+__device__ __forceinline__ void tail_row_left(TailAcc &a, float brow, float left, bool has_left, int k, bool want_quality)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float p = __uint_as_float(c_dct_t.v[k * 16 + i]) * brow;
+        a.t[i] = a.t[i] + p;
+    }
+    if (want_quality) {
+        const float gh = truncf(fabsf(((left - brow) * 100.0f) / 255.0f));
+        const float gv = truncf(fabsf(((a.prev - brow) * 100.0f) / 255.0f));
+        a.qsum += has_left ? gh : 0.0f;
+        a.qsum += (k > 0) ? gv : 0.0f;
+    }
+    a.prev = brow;
+}
+
 // lds: TAIL_LDS_FLOATS floats private to this wave.  Outputs are per-image pointers (nullable).
 __device__ __forceinline__ void tail_finish(TailAcc &a, float *lds, int lane, uint8_t *hash32, float *quality, float *coeffs,
                                             uint8_t *dihedral)

@@ -175,7 +175,7 @@ __device__ __forceinline__ int32_t luma_lds(const uint8_t *p, int i)
 template <int CH, int WMAX, int NIT>
 __global__ void __launch_bounds__(256) resize_fused_kernel(const uint8_t *__restrict__ px, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride,
                                                            uint32_t nw, uint32_t nh, DevAxis ax, DevAxis ay, uint32_t th, uint32_t tile_rows, uint32_t raw_pitch,
-                                                           uint8_t *__restrict__ dst)
+                                                           uint8_t *__restrict__ dst, uint32_t dst_pitch)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t rz_tile[];  // [tile_rows][RZ_TW], then [4 waves][RB][raw_pitch] row buffers
     constexpr int RB = 4;  // rows in flight per wave
@@ -249,20 +249,20 @@ __global__ void __launch_bounds__(256) resize_fused_kernel(const uint8_t *__rest
             const uint8_t *col = rz_tile + ys * RZ_TW + lane;
             int32_t ss = half;
             for (uint32_t i = 0; i < yn; i++) ss += (int32_t)col[i * RZ_TW] * (int32_t)k[i];
-            dst[((size_t)img * nh + r) * nw + o] = clip8(ss, ay.precision);
+            dst[((size_t)img * nh + r) * dst_pitch + o] = clip8(ss, ay.precision);
         }
     }
 }
 
 template <int CH, int NIT>
 void launch_resize_fused_n(dim3 grid, size_t lds, hipStream_t stream, const uint8_t *src, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride, uint32_t nw,
-                           uint32_t nh, const DevAxis &dx, const DevAxis &dy, uint32_t th, uint32_t tile_rows, uint32_t raw_pitch, uint8_t *dst)
+                           uint32_t nh, const DevAxis &dx, const DevAxis &dy, uint32_t th, uint32_t tile_rows, uint32_t raw_pitch, uint8_t *dst, uint32_t dst_pitch)
 {
     switch (dx.window) {
-    case 3: hipLaunchKernelGGL((resize_fused_kernel<CH, 3, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst); break;
-    case 5: hipLaunchKernelGGL((resize_fused_kernel<CH, 5, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst); break;
-    case 7: hipLaunchKernelGGL((resize_fused_kernel<CH, 7, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst); break;
-    default: hipLaunchKernelGGL((resize_fused_kernel<CH, 0, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst); break;
+    case 3: hipLaunchKernelGGL((resize_fused_kernel<CH, 3, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst, dst_pitch); break;
+    case 5: hipLaunchKernelGGL((resize_fused_kernel<CH, 5, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst, dst_pitch); break;
+    case 7: hipLaunchKernelGGL((resize_fused_kernel<CH, 7, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst, dst_pitch); break;
+    default: hipLaunchKernelGGL((resize_fused_kernel<CH, 0, NIT>), grid, dim3(256), lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst, dst_pitch); break;
     }
 }
 
@@ -270,10 +270,10 @@ constexpr int RZ_NIT_MAX = 8;  // staged rows of up to 8 x 256 bytes
 
 template <int CH>
 void launch_resize_fused(dim3 grid, size_t lds, hipStream_t stream, const uint8_t *src, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride, uint32_t nw,
-                         uint32_t nh, const DevAxis &dx, const DevAxis &dy, uint32_t th, uint32_t tile_rows, uint32_t raw_pitch, uint8_t *dst)
+                         uint32_t nh, const DevAxis &dx, const DevAxis &dy, uint32_t th, uint32_t tile_rows, uint32_t raw_pitch, uint8_t *dst, uint32_t dst_pitch)
 {
     const uint32_t nit = (raw_pitch / 4 + 63) / 64;
-#define RZ_GO(N) launch_resize_fused_n<CH, N>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst)
+#define RZ_GO(N) launch_resize_fused_n<CH, N>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, dst, dst_pitch)
     if (nit <= 1) RZ_GO(1);
     else if (nit <= 2) RZ_GO(2);
     else if (nit <= 3) RZ_GO(3);
@@ -385,7 +385,9 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
     }
     const bool fused = may_fuse && (size_t)tile_rows * RZ_TW <= 32768 && (nh + th - 1) / th <= 65535 && raw_pitch <= (uint32_t)RZ_NIT_MAX * 256;
 
-    const size_t full = fused ? 0 : (size_t)w * h, tmp = fused ? 0 : (size_t)nw * h, small = (size_t)nw * nh;
+    // the thumbnail's rows start on 16-byte boundaries where the streaming hasher (pdq_stream.hip) reads them as whole dwords
+    const uint32_t np = fused ? (nw + 15u) & ~15u : nw;
+    const size_t full = fused ? 0 : (size_t)w * h, tmp = fused ? 0 : (size_t)nw * h, small = (size_t)np * nh;
     uint32_t chunk = (uint32_t)std::max<size_t>(1, (fused ? (size_t)1 << 30 : (size_t)256 << 20) / (fused ? small * 4 : full));  // (fused: as many images as the hasher takes per launch)
     chunk = std::min(std::min(chunk, n), 65535u);
     const size_t need = (full + tmp + small) * chunk;
@@ -408,11 +410,11 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
             const uint8_t *src = d_px + (size_t)first * image_stride;
             const size_t lds = (((size_t)tile_rows * RZ_TW + 15) & ~(size_t)15) + (size_t)4 * 4 * raw_pitch;
             if (channels == 1)
-                launch_resize_fused<1>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small);
+                launch_resize_fused<1>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small, np);
             else if (channels == 3)
-                launch_resize_fused<3>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small);
+                launch_resize_fused<3>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small, np);
             else
-                launch_resize_fused<4>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small);
+                launch_resize_fused<4>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small, np);
         } else {
         hipLaunchKernelGGL(luma_u8_kernel, dim3(grid_for((uint64_t)m * full)), dim3(256), 0, stream, d_px + (size_t)first * image_stride, m, w,
                            h, channels, row_stride, image_stride, p_luma);
@@ -422,7 +424,17 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
         RPH_HIP_CHECK(hipGetLastError());
         // generate_pdq_from_luma on the thumbnail (no second size check in the reference: a 4000x5 input is hashed from 512x1).
         // It records scratch_done on `stream` when it is through, which also covers the planes above.
-        rc = rph_launch_pdq_generic(ctx, (const uint8_t *)p_small, m, nw, nh, 1, nw, small, d_hash + (size_t)first * 32,
+        if (ctx->pdq_kernel != 5 && ctx->pdq_kernel != 0 && rph_pdq_stream_supported(p_small, nw, nh, 1, np, small)) {  // one streaming kernel per thumbnail
+            rc = rph_launch_pdq_stream(ctx, (const uint8_t *)p_small, m, nw, nh, np, small, d_hash + (size_t)first * 32, d_quality ? d_quality + first : nullptr,
+                                       d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr, d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr,
+                                       d_valid ? d_valid + first : nullptr, stream);
+            if (rc != RPH_OK) return rc;
+            RPH_HIP_CHECK(hipEventRecord(ctx->scratch_done, stream));  // (the multi-pass hasher records it itself)
+            ctx->scratch_stream = stream;
+            ctx->scratch_used = true;
+            continue;
+        }
+        rc = rph_launch_pdq_generic(ctx, (const uint8_t *)p_small, m, nw, nh, 1, np, small, d_hash + (size_t)first * 32,
                                     d_quality ? d_quality + first : nullptr, d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr,
                                     d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr, d_valid ? d_valid + first : nullptr, stream);
         if (rc != RPH_OK) return rc;
