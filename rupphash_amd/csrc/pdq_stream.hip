@@ -328,8 +328,10 @@ __global__ void __launch_bounds__(64, 2) pdq_stream_kernel(const uint8_t *__rest
 #pragma unroll
     for (int i = 0; i < 8; i++) lds[ST_OFF_SUMS + 64 * i + w.lane] = 0.0f;
 
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(px + (size_t)img * image_stride), 0, (int)((size_t)(g.H - 1) * row_stride + (size_t)g.W), 0x00027000);
+    // The range check works on whole dwords: the image ends with the aligned dword that holds its last pixel (rows start on dword
+    // boundaries, so that dword never leaves the page of the last pixel; what follows the pixel in it is under no window).
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(px + (size_t)img * image_stride), 0,
+                                                                        (int)((size_t)(g.H - 1) * row_stride + (((size_t)g.W + 3) & ~(size_t)3)), 0x00027000);
 
     int ni = 0;  // next kept row (decimate_float's row index)
 #pragma unroll 1
@@ -392,12 +394,90 @@ __global__ void __launch_bounds__(64, 2) pdq_stream_kernel(const uint8_t *__rest
     if (valid && w.lane == 0) valid[img] = 1;
 }
 
+// to_luma601 (pdqhash.rs:268-284) of Rgb8 / Rgba8 pixels into a Luma8 plane with 16-byte aligned rows: four pixels per thread, whole dwords in
+// and out.  The streaming kernel takes its A operand -- 16 luma bytes per lane -- straight from memory, so colour inputs pass through this
+// plane (read 3 or 4 bytes, write 1, read 1 per pixel).
+template <int CH>
+__global__ void __launch_bounds__(256) st_luma_kernel(const uint8_t *__restrict__ px, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride,
+                                                      uint8_t *__restrict__ out, uint32_t out_pitch, size_t out_stride)
+{
+    const uint32_t quads = (w + 3) / 4;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= quads * h) return;
+    const uint32_t y = t / quads, q = t - y * quads;
+    const uint8_t *p = px + (size_t)blockIdx.y * image_stride + (size_t)y * row_stride + (size_t)q * 4 * CH;
+    uint32_t d[CH];
+    if (q * 4 + 4 <= w) {
+#pragma unroll
+        for (int i = 0; i < CH; i++) d[i] = reinterpret_cast<const uint32_t *>(p)[i];
+    } else {  // the row's last, partial quad: byte by byte, nothing is read behind the row
+#pragma unroll
+        for (int i = 0; i < CH; i++) d[i] = 0;
+        for (uint32_t b = 0; b < (w - q * 4) * CH; b++) d[b >> 2] |= (uint32_t)p[b] << (8 * (b & 3));
+    }
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int B = i * CH;
+        const uint32_t r = (d[B >> 2] >> (8 * (B & 3))) & 0xFFu, g = (d[(B + 1) >> 2] >> (8 * ((B + 1) & 3))) & 0xFFu, b = (d[(B + 2) >> 2] >> (8 * ((B + 2) & 3))) & 0xFFu;
+        o |= ((299u * r + 587u * g + 114u * b + 500u) / 1000u) << (8 * i);
+    }
+    reinterpret_cast<uint32_t *>(out + (size_t)blockIdx.y * out_stride + (size_t)y * out_pitch)[q] = o;
+}
+
 }  // namespace
 
 bool rph_pdq_stream_supported(const uint8_t *d_px, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride, size_t image_stride)
 {
     return channels == 1 && w >= 128 && w <= 512 && h >= 128 && h <= 512 && (row_stride % 4) == 0 && (image_stride % 4) == 0 && ((uintptr_t)d_px % 4) == 0 &&
            (size_t)h * row_stride < ((size_t)1 << 30);
+}
+
+// Rgb8 / Rgba8 images of the same geometries: a Luma8 plane in the context's scratch, then the streaming kernel.  Called with ctx->mu held.
+bool rph_pdq_stream_color_supported(const uint8_t *d_px, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride, size_t image_stride)
+{
+    return (channels == 3 || channels == 4) && w >= 128 && w <= 512 && h >= 128 && h <= 512 && (row_stride % 4) == 0 && (image_stride % 4) == 0 &&
+           ((uintptr_t)d_px % 4) == 0;
+}
+
+int rph_launch_pdq_stream_color(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride, size_t image_stride,
+                                uint8_t *d_hash, float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream)
+{
+    if (n == 0) return RPH_OK;
+    const uint32_t pitch = (w + 15u) & ~15u;
+    const size_t plane = (size_t)pitch * h;
+    uint32_t chunk = (uint32_t)(((size_t)1 << 30) / plane);
+    chunk = chunk > n ? n : (chunk > 65535u ? 65535u : chunk);
+    const size_t need = plane * chunk;
+    if (ctx->scratch_bytes < need) {
+        RPH_HIP_CHECK(hipDeviceSynchronize());  // kernels of any stream may still be using the old scratch
+        if (ctx->scratch) RPH_HIP_CHECK(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        RPH_HIP_CHECK(hipMalloc((void **)&ctx->scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    if (!ctx->scratch_done) RPH_HIP_CHECK(hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));
+    if (ctx->scratch_used && ctx->scratch_stream != stream) RPH_HIP_CHECK(hipStreamWaitEvent(stream, ctx->scratch_done, 0));
+    uint8_t *luma = reinterpret_cast<uint8_t *>(ctx->scratch);
+    const uint32_t quads = (w + 3) / 4;
+    for (uint32_t first = 0; first < n; first += chunk) {
+        const uint32_t m = (n - first) < chunk ? (n - first) : chunk;
+        const dim3 grid((quads * h + 255) / 256, m);
+        const uint8_t *src = d_px + (size_t)first * image_stride;
+        if (channels == 3)
+            hipLaunchKernelGGL(st_luma_kernel<3>, grid, dim3(256), 0, stream, src, w, h, row_stride, image_stride, luma, pitch, plane);
+        else
+            hipLaunchKernelGGL(st_luma_kernel<4>, grid, dim3(256), 0, stream, src, w, h, row_stride, image_stride, luma, pitch, plane);
+        hipLaunchKernelGGL(pdq_stream_kernel, dim3(m), dim3(64), 0, stream, (const uint8_t *)luma, m, w, h, (size_t)pitch, plane, d_hash + (size_t)first * 32,
+                           d_quality ? d_quality + first : nullptr, d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr,
+                           d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr, d_valid ? d_valid + first : nullptr);
+        RPH_HIP_CHECK(hipGetLastError());
+    }
+    RPH_HIP_CHECK(hipEventRecord(ctx->scratch_done, stream));
+    ctx->scratch_stream = stream;
+    ctx->scratch_used = true;
+    return RPH_OK;
 }
 
 int rph_launch_pdq_stream(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride, uint8_t *d_hash,

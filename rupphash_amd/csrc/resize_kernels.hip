@@ -19,6 +19,8 @@ namespace {
 struct Axis {
     std::vector<uint32_t> start, size;
     std::vector<int16_t> coef;  // [out][window]
+    std::vector<int32_t> c1;    // the one coefficient of every tap of an output (a box: the taps of a window weigh the same)
+    bool uniform = true;        // ... which holds for every output
     int window = 0, precision = 0;
 };
 
@@ -71,12 +73,19 @@ Axis build_axis(uint32_t in_size, uint32_t out_size)
     }
     a.coef.resize(w.size());
     for (size_t i = 0; i < w.size(); i++) a.coef[i] = (int16_t)std::llround(w[i] * (double)(1 << a.precision));
+    a.c1.assign(out_size, 0);
+    for (uint32_t o = 0; o < out_size; o++) {
+        const int16_t *k = &a.coef[(size_t)o * a.window];
+        a.c1[o] = a.size[o] ? k[0] : 0;
+        for (uint32_t i = 1; i < a.size[o]; i++) a.uniform = a.uniform && k[i] == k[0];
+    }
     return a;
 }
 
 struct DevAxis {
     const uint32_t *start, *size;
     const int16_t *coef;
+    const int32_t *c1;
     int window, precision;
 };
 
@@ -254,6 +263,142 @@ __global__ void __launch_bounds__(256) resize_fused_kernel(const uint8_t *__rest
     }
 }
 
+// ---- both passes on the matrix pipe (Luma8 sources; the default).  A box convolution is a window SUM times one coefficient:
+//   clip8((half + sum_i in[start + i] * k) >> p)  =  clip8((half + k * S) >> p),  S = the window sum (integer arithmetic: the same number),
+// and window sums of many outputs are one product with a 0/1 band matrix.  One wave owns 32 output rows x 64 output columns:
+//   pass 1  v_mfma_i32_32x32x32_i8, A = 32 source rows x 32 source bytes straight from memory (lane = row), B = the band matrix of 32 output
+//           columns: the sums arrive with lane = output column and the 32 source rows spread over 16 registers x 2 lane halves -- rounded,
+//           clipped and packed to bytes that is exactly the B operand layout of
+//   pass 2  the same instruction with A = the band matrix of the 32 output rows over those 32 source rows: lane = output column, registers =
+//           output rows; v_permlane32_swap gives every lane all 32 rows of one of the 64 columns, and a row is stored as 64 adjacent bytes.
+// Nothing goes through LDS.  (Bytes are unsigned, the instruction is signed: operands ^ 0x80, and 128 x the window size comes back in the
+// rounding constant.)  Rows of any alignment: aligned dwords + v_alignbyte, so the range check of the buffer resource never cuts a pixel.
+typedef int rz_v4i __attribute__((ext_vector_type(4)));
+typedef int rz_v16i __attribute__((ext_vector_type(16)));
+typedef unsigned int rz_v4u __attribute__((ext_vector_type(4)));
+
+// bits [lo, hi) of a 16-slot group as 16 bytes of 0 / 1
+__device__ __forceinline__ rz_v4i band16(int lo, int hi)
+{
+    lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+    hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+    const uint32_t m = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    rz_v4i r;
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = (int)((((m >> (4 * q)) & 15u) * 0x00204081u) & 0x01010101u);
+    return r;
+}
+
+__global__ void __launch_bounds__(64) resize_mfma_kernel(const uint8_t *__restrict__ px, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride, uint32_t nw,
+                                                         uint32_t nh, DevAxis ax, DevAxis ay, uint8_t *__restrict__ dst, uint32_t dst_pitch, size_t dst_stride)
+{
+    const int lane = threadIdx.x, n = lane & 31, kh = lane >> 5;
+    const uint32_t img = blockIdx.z, r0 = blockIdx.y * 32, o0 = blockIdx.x * 64;
+    // the image as a buffer of whole dwords around its bytes
+    const uint8_t *base = px + (size_t)img * image_stride;
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(base) & 3u);
+    const uint32_t bytes = (uint32_t)((size_t)(h - 1) * row_stride + w);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base - mis), 0, (int)((mis + bytes + 3u) & ~3u), 0x00027000);
+
+    // source window of the task (uniform)
+    const uint32_t o_last = min(o0 + 63u, nw - 1u), r_last = min(r0 + 31u, nh - 1u);
+    const int x_lo = (int)ax.start[o0] & ~15, x_hi = (int)(ax.start[o_last] + ax.size[o_last]);
+    const int y_lo = (int)ay.start[r0], y_hi = (int)(ay.start[r_last] + ay.size[r_last]);
+    const int n_ks = (x_hi - x_lo + 31) / 32, n_yb = (y_hi - y_lo + 31) / 32;
+
+    // per-lane tables of pass 1: the two column blocks' windows in slots of the lane's own half, coefficient and rounding constant
+    int xs[2], xe[2], cx[2], c0[2], ks_lo[2], ks_hi[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        const uint32_t o = o0 + 32 * cb + n, oc = min(o, nw - 1u);
+        const int st = (int)ax.start[oc], sz = o < nw ? (int)ax.size[oc] : 0;
+        xs[cb] = st - x_lo - 16 * kh;
+        xe[cb] = xs[cb] + sz;
+        cx[cb] = ax.c1[oc];
+        c0[cb] = (1 << (ax.precision - 1)) + 128 * sz * cx[cb];
+        // K steps that meet this block's windows (uniform)
+        const uint32_t ob0 = min(o0 + 32u * cb, nw - 1u), ob1 = min(o0 + 32u * cb + 31u, nw - 1u);
+        ks_lo[cb] = ((int)ax.start[ob0] - x_lo) / 32;
+        ks_hi[cb] = ((int)(ax.start[ob1] + ax.size[ob1]) - x_lo + 31) / 32;
+        if (o0 + 32u * cb >= nw) ks_hi[cb] = ks_lo[cb] = 0;
+    }
+    // pass 2: this lane's output row as an A-operand row, its window relative to the first source row
+    const uint32_t rr = min(r0 + (uint32_t)n, nh - 1u);
+    const int ys = (int)ay.start[rr] - y_lo, ye = ys + (r0 + (uint32_t)n < nh ? (int)ay.size[rr] : 0);
+
+    rz_v16i acc2[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) acc2[cb] = rz_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+#pragma unroll 1
+    for (int b = 0; b < n_yb; b++) {
+        const int yb = y_lo + 32 * b, y = yb + n;
+        const bool row_ok = y < y_hi && y < (int)h;
+        const uint32_t row_off = mis + (uint32_t)y * (uint32_t)row_stride + (uint32_t)x_lo + 16u * (uint32_t)kh;
+        rz_v16i acc1[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) acc1[cb] = rz_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+        for (int ks = 0; ks < n_ks; ks++) {
+            const uint32_t a = row_off + 32u * (uint32_t)ks, al = row_ok ? a & ~3u : 0x80000000u, sh = a & 3u;
+            const rz_v4u d4 = __builtin_amdgcn_raw_buffer_load_b128(rs, al, 0, 0);
+            const uint32_t d5 = __builtin_amdgcn_raw_buffer_load_b32(rs, al + 16u, 0, 0);
+            rz_v4i av;
+            av[0] = (int)(__builtin_amdgcn_alignbyte(d4[1], d4[0], sh) ^ 0x80808080u);
+            av[1] = (int)(__builtin_amdgcn_alignbyte(d4[2], d4[1], sh) ^ 0x80808080u);
+            av[2] = (int)(__builtin_amdgcn_alignbyte(d4[3], d4[2], sh) ^ 0x80808080u);
+            av[3] = (int)(__builtin_amdgcn_alignbyte(d5, d4[3], sh) ^ 0x80808080u);
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+                if (ks >= ks_lo[cb] && ks < ks_hi[cb]) acc1[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, band16(xs[cb] - 32 * ks, xe[cb] - 32 * ks), acc1[cb], 0, 0, 0);
+            }
+        }
+        // band matrix of the output rows over source rows yb + 8 q + 4 kh + i (slot (kh, 4 q + i))
+        rz_v4i by;
+        {
+            const int lo = ys - 32 * b, hi = ye - 32 * b;
+            const int l2 = lo < 0 ? 0 : (lo > 32 ? 32 : lo), h2 = hi < 0 ? 0 : (hi > 32 ? 32 : hi);
+            const uint32_t m = h2 > l2 ? (uint32_t)((1ull << h2) - 1ull) & ~(uint32_t)((1ull << l2) - 1ull) : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) by[q] = (int)((((m >> (8 * q + 4 * kh)) & 15u) * 0x00204081u) & 0x01010101u);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+            rz_v4i hb;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t d = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    int v = (acc1[cb][4 * q + i] * cx[cb] + c0[cb]) >> ax.precision;
+                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    d |= (uint32_t)v << (8 * i);
+                }
+                hb[q] = (int)(d ^ 0x80808080u);
+            }
+            acc2[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(by, hb, acc2[cb], 0, 0, 0);
+        }
+    }
+    // lane l: column o0 + l; rows r0 + 8 q + i from P[4 q + i], r0 + 8 q + 4 + i from R[4 q + i]
+    const uint32_t o = o0 + (uint32_t)lane;
+    uint8_t *out = dst + (size_t)img * dst_stride + o;
+    const int half_y = 1 << (ay.precision - 1);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(acc2[0][j], acc2[1][j], false, false);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint32_t r = r0 + 8u * (uint32_t)(j >> 2) + 4u * (uint32_t)t + (uint32_t)(j & 3);
+            if (r < nh) {  // (uniform)
+                const int cy = ay.c1[r], sz = (int)ay.size[r];
+                int v = (((int)sw[t] + 128 * sz) * cy + half_y) >> ay.precision;
+                v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                if (o < nw) out[(size_t)r * dst_pitch] = (uint8_t)v;
+            }
+        }
+    }
+}
+
 template <int CH, int NIT>
 void launch_resize_fused_n(dim3 grid, size_t lds, hipStream_t stream, const uint8_t *src, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride, uint32_t nw,
                            uint32_t nh, const DevAxis &dx, const DevAxis &dy, uint32_t th, uint32_t tile_rows, uint32_t raw_pitch, uint8_t *dst, uint32_t dst_pitch)
@@ -289,8 +434,9 @@ void launch_resize_fused(dim3 grid, size_t lds, hipStream_t stream, const uint8_
 namespace {
 struct DevAxisOwner {
     DevAxis ax{};
-    void *start = nullptr, *size = nullptr, *coef = nullptr;
+    void *start = nullptr, *size = nullptr, *coef = nullptr, *c1 = nullptr;
     std::vector<uint32_t> h_start, h_size;  // host copies: the fused kernel's tile height is chosen from them
+    bool uniform = false;
 };
 struct AxisCache {
     std::map<std::pair<uint32_t, uint32_t>, DevAxisOwner> axes;  // (in_size, out_size) -> tables
@@ -309,6 +455,7 @@ int device_axis(rph_ctx *ctx, uint32_t in_size, uint32_t out_size, DevAxis &out,
                 (void)hipFree(kv.second.start);
                 (void)hipFree(kv.second.size);
                 (void)hipFree(kv.second.coef);
+                (void)hipFree(kv.second.c1);
             }
             c.axes.clear();
         }
@@ -320,7 +467,10 @@ int device_axis(rph_ctx *ctx, uint32_t in_size, uint32_t out_size, DevAxis &out,
         RPH_HIP_CHECK(hipMemcpy(o.start, a.start.data(), a.start.size() * 4, hipMemcpyHostToDevice));  // synchronous: once per geometry
         RPH_HIP_CHECK(hipMemcpy(o.size, a.size.data(), a.size.size() * 4, hipMemcpyHostToDevice));
         RPH_HIP_CHECK(hipMemcpy(o.coef, a.coef.data(), a.coef.size() * 2, hipMemcpyHostToDevice));
-        o.ax = DevAxis{(const uint32_t *)o.start, (const uint32_t *)o.size, (const int16_t *)o.coef, a.window, a.precision};
+        RPH_HIP_CHECK(hipMalloc(&o.c1, a.c1.size() * 4));
+        RPH_HIP_CHECK(hipMemcpy(o.c1, a.c1.data(), a.c1.size() * 4, hipMemcpyHostToDevice));
+        o.uniform = a.uniform;
+        o.ax = DevAxis{(const uint32_t *)o.start, (const uint32_t *)o.size, (const int16_t *)o.coef, (const int32_t *)o.c1, a.window, a.precision};
         o.h_start = a.start;
         o.h_size = a.size;
         it = c.axes.emplace(std::make_pair(in_size, out_size), std::move(o)).first;
@@ -339,6 +489,7 @@ void rph_resize_forget(rph_ctx *ctx)
             (void)hipFree(kv.second.start);
             (void)hipFree(kv.second.size);
             (void)hipFree(kv.second.coef);
+            (void)hipFree(kv.second.c1);
         }
         delete c;
         ctx->axis_cache = nullptr;
@@ -409,7 +560,10 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
             const dim3 grid((nw + RZ_TW - 1) / RZ_TW, (nh + th - 1) / th, m);
             const uint8_t *src = d_px + (size_t)first * image_stride;
             const size_t lds = (((size_t)tile_rows * RZ_TW + 15) & ~(size_t)15) + (size_t)4 * 4 * raw_pitch;
-            if (channels == 1)
+            if (channels == 1 && ox->uniform && oy->uniform && ctx->pdq_kernel != 5 && (size_t)h * row_stride < ((size_t)1 << 31))
+                hipLaunchKernelGGL(resize_mfma_kernel, dim3((nw + 63) / 64, (nh + 31) / 32, m), dim3(64), 0, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy,
+                                   p_small, np, small);
+            else if (channels == 1)
                 launch_resize_fused<1>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small, np);
             else if (channels == 3)
                 launch_resize_fused<3>(grid, lds, stream, src, w, h, row_stride, image_stride, nw, nh, dx, dy, th, tile_rows, raw_pitch, p_small, np);

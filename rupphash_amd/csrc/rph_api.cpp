@@ -359,6 +359,9 @@ int rph_pdq_hash_batch_dev(rph_ctx *ctx, const void *d_px, uint32_t n, uint32_t 
         return rph_launch_pdq_stream(ctx, (const uint8_t *)d_px, n, w, h, row_stride, image_stride, (uint8_t *)d_hash32, (float *)d_quality, (float *)d_coeffs,
                                      (uint8_t *)d_dihedral, (uint8_t *)d_valid, s);
     }
+    if (ctx->pdq_kernel >= 1 && ctx->pdq_kernel != 5 && rph_pdq_stream_color_supported((const uint8_t *)d_px, w, h, channels, row_stride, image_stride))
+        return rph_launch_pdq_stream_color(ctx, (const uint8_t *)d_px, n, w, h, channels, row_stride, image_stride, (uint8_t *)d_hash32, (float *)d_quality,
+                                           (float *)d_coeffs, (uint8_t *)d_dihedral, (uint8_t *)d_valid, s);
     return rph_launch_pdq_generic(ctx, (const uint8_t *)d_px, n, w, h, channels, row_stride, image_stride, (uint8_t *)d_hash32,
                                   (float *)d_quality, (float *)d_coeffs, (uint8_t *)d_dihedral, (uint8_t *)d_valid, s);
 }

@@ -95,6 +95,9 @@ int rph_launch_pdq_fused512(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, size_
 bool rph_pdq_stream_supported(const uint8_t *d_px, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride, size_t image_stride);
 int rph_launch_pdq_stream(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride, uint8_t *d_hash,
                           float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream);
+bool rph_pdq_stream_color_supported(const uint8_t *d_px, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride, size_t image_stride);
+int rph_launch_pdq_stream_color(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride, size_t image_stride,
+                                uint8_t *d_hash, float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream);
 int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels,
                            size_t row_stride, size_t image_stride, uint8_t *d_hash, float *d_quality, float *d_coeffs,
                            uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream);

@@ -36,9 +36,25 @@ def contents(rng, n, h, w):
     return imgs
 
 
+def hash_padded(eng, imgs, pad_value=0xA5):
+    """Luma8 images through the C ABI with rows padded to whole dwords (what the streaming kernel takes: a packed row of odd width would go to
+    the multi-pass kernels); the pad bytes are not zero"""
+    from rupphash_amd._lib import check as rc_check
+
+    n, h, w = imgs.shape
+    pitch = (w + 3) & ~3
+    buf = np.full((n, h, pitch), pad_value, np.uint8)
+    buf[:, :, :w] = imgs
+    out = {"hash": np.zeros((n, 32), np.uint8), "quality": np.zeros(n, np.float32), "coeffs": np.zeros((n, 256), np.float32),
+           "dihedral": np.zeros((n, 8, 32), np.uint8), "valid": np.zeros(n, np.uint8)}
+    rc_check(eng.L.rph_pdq_hash_batch(eng.ctx, buf.ctypes.data, n, w, h, 1, pitch, pitch * h, out["hash"].ctypes.data, out["quality"].ctypes.data,
+                                      out["coeffs"].ctypes.data, out["dihedral"].ctypes.data, out["valid"].ctypes.data), "rph_pdq_hash_batch")
+    return out
+
+
 def check(eng, oracle, imgs, which=4):
     eng.set_pdq_kernel(which)
-    out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
+    out = hash_padded(eng, imgs) if imgs.ndim == 3 else eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
     eng.set_pdq_kernel(4)
     for k in range(len(imgs)):
         rc, coeffs, q = oracle.pdq_features(imgs[k])
@@ -98,3 +114,20 @@ def test_stream_kernel_strided_rows_and_many_images(eng, oracle):
         assert rc == 0 and np.array_equal(bits(coeffs[k]), bits(c)), k
         assert bits(quality[k:k + 1])[0] == bits(np.float32(q))[()]
         assert np.array_equal(hashes[k], oracle.to_hash(c))
+
+
+@pytest.mark.parametrize("w,h,ch", [(512, 344, 3), (344, 512, 4), (129, 131, 3), (130, 258, 4), (511, 509, 3), (300, 200, 3), (512, 128, 4), (203, 307, 3)])
+def test_stream_kernel_colour_inputs(eng, oracle, w, h, ch):
+    """Rgb8 / Rgba8 of the same geometries: to_luma601 (pdqhash.rs:268-284) into a Luma8 plane, then the streaming kernel; widths that are
+    not multiples of four end in a partial quad"""
+    rng = np.random.default_rng(w * 31 + h + ch)
+    imgs = rng.integers(0, 256, (4, h, w, ch), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs[0, ..., 0] = ((xx * 255) // (w - 1)).astype(np.uint8)
+    imgs[1, ..., 1] = ((yy * 255) // (h - 1)).astype(np.uint8)
+    imgs[2] = 255
+    out = check(eng, oracle, imgs)
+    eng.set_pdq_kernel(5)
+    ref = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
+    eng.set_pdq_kernel(4)
+    assert np.array_equal(bits(out["coeffs"]), bits(ref["coeffs"])) and np.array_equal(out["hash"], ref["hash"])
