@@ -4,13 +4,16 @@
 A "step" is one pass of the hot path over one resident batch:
   phase A (-> `value`): PDQ-hash `--images` synthetic 512x512 RGB8 images per GPU (BASELINE config 2:
            100 000 images on 1 GPU; weak scaling: every rank hashes its own 100 000);
-  phase C (-> `e2e`):   BASELINE config 4 as ONE timed region over the same resident images: hash (hash + quality +
+  phase C (-> `e2e`):   BASELINE config 4 as ONE timed region over resident images: hash (hash + quality +
            8 dihedral hashes) -> RCCL all-gather of the per-file hash blocks -> every rank sweeps its share of the block
            pairs with the production rule of group_files_generic (8 variants, low-quality rule) -> edges to rank 0 ->
-           union-find; the near-duplicate pairs of the synthetic sequence (k % 1000 == 999) must come out as groups;
+           union-find; the near-duplicate pairs of the synthetic sequence (k % 1000 == 999) must come out as groups.
+           N > 1: 1 000 000 images in all, 1 000 000 / N per GPU (config 4 at its stated size; capped at 250 000 per GPU =
+           197 GB of pixels, so N = 2 runs 500 000); N = 1: the 100 000 images of phase A;
   phase B (-> `hamming`): all-pairs 256-bit Hamming sweep, threshold 32, over 1M*sqrt(N) synthetic
            hashes (BASELINE config 3 at N=1; per-GPU pair count fixed as N grows): every rank generates
-           its shard, one RCCL all-gather of the hash shards, then each rank sweeps its share of the tile pairs.
+           its shard, one RCCL all-gather of the hash shards, then each rank sweeps its share of the tile pairs;
+           (-> `hamming_10m`): BASELINE config 5, strong scaling: 10 000 000 hashes split over the ranks, same steps.
 Inputs are generated on the device and resident in HBM before the timed regions.
 One JSON line on rank 0.  Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either start it under
 torch.distributed.run (one process per GPU), or just run `python bench.py --gpus N`: with WORLD_SIZE unset it starts
@@ -82,6 +85,10 @@ def parse_args():
                     "workloads free of other launches of the same kernels)")
     ap.add_argument("--no-e2e", action="store_true", help="skip phase C (config 4 as one timed region)")
     ap.add_argument("--e2e-steps", type=int, default=3)
+    ap.add_argument("--e2e-total", type=int, default=1_000_000, help="images of the e2e leg over all GPUs when N > 1 (BASELINE config 4)")
+    ap.add_argument("--e2e-max-per-gpu", type=int, default=250_000, help="cap of resident images per GPU in the e2e leg (250 000 = 197 GB)")
+    ap.add_argument("--hashes-strong", type=int, default=10_000_000, help="hashes of the strong-scaling sweep over all GPUs (BASELINE config 5); 0 = skip")
+    ap.add_argument("--strong-steps", type=int, default=3)
     ap.add_argument("--only", default="", help="comma list of phases to run: pdq, e2e, hamming (default: all)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget per cpu_baseline leg")
     ap.add_argument("--jpeg-files", type=int, default=100_000, help="files per call of the JPEG leg (SURVEY 8f row N3; rank 0 at N = 1 only)")
@@ -103,7 +110,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    phases = set(p for p in args.only.split(",") if p) or {"pdq", "e2e", "hamming", "jpeg"}
+    phases = set(p for p in args.only.split(",") if p) or {"pdq", "e2e", "hamming", "hamming_10m", "jpeg"}
+    if args.hashes_strong <= 0:
+        phases.discard("hamming_10m")
     if args.no_e2e:
         phases.discard("e2e")
     if args.no_jpeg:
@@ -182,7 +191,12 @@ def main():
 
     # ------------------------------------------------------------------ phase A: PDQ hashing
     n_img = args.images
-    imgs = torch.empty((n_img, IMG_BYTES), dtype=torch.uint8, device=dev)
+    # the e2e leg (config 4) at N > 1 holds 1 000 000 / N images per GPU (capped); one buffer serves both legs
+    e2e_total = n_img if world == 1 else min(args.e2e_total, args.e2e_max_per_gpu * world)
+    e2e_lo, e2e_hi = D.shard_range(e2e_total, rank, world)
+    n_buf = max(n_img, e2e_hi - e2e_lo) if "e2e" in phases else n_img
+    imgs_all = torch.empty((n_buf, IMG_BYTES), dtype=torch.uint8, device=dev)
+    imgs = imgs_all[:n_img]
     hashes = torch.empty((n_img, 32), dtype=torch.uint8, device=dev)
     first_k = rank * n_img  # every rank hashes its own contiguous range of the global image sequence
     eng.synth_images_dev(imgs.data_ptr(), first_k, n_img, 512, 512, stream=stream)
@@ -225,7 +239,7 @@ def main():
             eng.event_destroy(ra)
             eng.event_destroy(rb)
         hash_checksum = int(hashes.to(torch.int64).sum().item())
-        pdq_sample = hashes[:64].cpu().numpy()
+        pdq_sample = hashes[:min(n_img, 30_000)].cpu().numpy()  # every image the CPU baseline hashes is compared
 
         # L2 -> fabric read bytes per launch: rocprofv3 cannot run inside this process, so the figure is the PMC measurement of this
         # same kernel committed under profiles/ (FETCH_SIZE, corrected as MI355X_MICROARCH.md prescribes and calibrated on the read
@@ -252,21 +266,37 @@ def main():
                          "traffic_counts": "L2->fabric read bytes (Infinity-Cache hits included)",
                          "kernel": "pdq_fused512_kernel" if args.pdq_kernel else "generic multi-pass", "kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_IMAGE * n_img,
-                         "measured_read_stream_gbs": read_gbs, "frac_of_measured_read_stream": (achieved_gbs / read_gbs) if read_gbs else None},
+                         "measured_read_stream_gbs": read_gbs, "frac_of_measured_read_stream": (achieved_gbs / read_gbs) if read_gbs else None,
+                         "mfma_utilisation": 0.0,
+                         "mfma_utilisation_note": "the bit-exact 64->16 DCT is a strictly ordered f32 mul-then-add chain (pdqhash.rs:306-336): f32 MFMA "
+                                                  "accumulates in another order and fuses, so the fused 512x512 kernel issues no matrix instruction "
+                                                  "(SQ_INSTS_VALU_MFMA_* = 0); the matrix pipe carries the window sums of the streaming kernel for "
+                                                  "other geometries (pdq_stream.hip) and the Hamming sweep"},
         })
 
     # ------------------------------------------------------------------ phase C: config 4 as one timed region
     if "e2e" in phases:
-        n_total = n_img * world
+        n_total = e2e_total
+        n_loc = e2e_hi - e2e_lo
+        e2e_imgs = imgs_all[:n_loc]
+        if world > 1:  # this rank's shard of the global sequence (untimed; the images are resident when the timed region starts)
+            eng.synth_images_dev(e2e_imgs.data_ptr(), e2e_lo, n_loc, 512, 512, stream=stream)
+            torch.cuda.synchronize()
         e2e_steps = max(1, args.e2e_steps)
         timings = {}
-        groups, info = D.hash_and_group_device(eng, imgs, n_total, args.threshold, dist, variants=True)  # warm-up (allocations, RCCL channels)
+        groups, info = D.hash_and_group_device(eng, e2e_imgs, n_total, args.threshold, dist, variants=True)  # warm-up (allocations, RCCL channels)
         barrier_sync()
         t0 = time.perf_counter()
         for _ in range(e2e_steps):
-            groups, info = D.hash_and_group_device(eng, imgs, n_total, args.threshold, dist, variants=True, timings=timings)
+            groups, info = D.hash_and_group_device(eng, e2e_imgs, n_total, args.threshold, dist, variants=True, timings=timings)
         barrier_sync()
         e2e_s = max_over_ranks(time.perf_counter() - t0) / e2e_steps
+        sweep_ms_max = max_over_ranks(timings.get("sweep_ms", 0.0))
+        hash_ms_max = max_over_ranks(timings.get("hash_ms", 0.0))
+        gather_ms_max = max_over_ranks(timings.get("allgather_ms", 0.0))
+        if world > 1:  # phase A's images back (the CPU baseline and the checksums refer to them; N > 1 runs no CPU baseline, but keep the state simple)
+            eng.synth_images_dev(imgs.data_ptr(), first_k, n_img, 512, 512, stream=stream)
+            torch.cuda.synchronize()
         if rank == 0:
             # image k of the global sequence with k % 1000 == 999 shares its block colours with image k - 1
             want_pairs = [[k - 1, k] for k in range(999, n_total, 1000)]
@@ -277,29 +307,34 @@ def main():
                 valid = False
                 problems.append(f"e2e: {len(groups)} groups, {len(missing)} of {len(want_pairs)} near-duplicate pairs missing")
             result["e2e"] = {
-                "workload": f"{n_total} synthetic 512x512 RGB8 images resident in HBM ({n_img} per GPU) -> PDQ hash + quality + 8 dihedral hashes -> "
+                "workload": f"{n_total} synthetic 512x512 RGB8 images resident in HBM ({n_loc} on rank 0) -> PDQ hash + quality + 8 dihedral hashes -> "
                             "all-gather of the per-file hash blocks -> variant sweep (group_files_generic rule) -> edges to rank 0 -> union-find "
-                            "(BASELINE config 4; 1M images at 8 GPUs with --images 125000)",
+                            "(BASELINE config 4" + (": 1 000 000 images" if n_total == 1_000_000 else f" at {n_total} images") + ")",
+                "is_baseline_config_4_size": n_total == 1_000_000, "scaling": "strong (total fixed)" if world > 1 else "one GPU",
                 "seconds_per_run": e2e_s, "images_per_s": n_total / e2e_s, "runs": e2e_steps, "similarity": args.threshold,
                 "groups": len(groups), "near_duplicate_pairs_expected": len(want_pairs), "near_duplicate_pairs_found": len(want_pairs) - len(missing),
                 "comparison_count": info["edges_total"], "ranks_in_collective": info["ranks_in_collective"],
-                "hash_and_exchange_s_rank0": timings.get("hash_and_exchange_s"), "all_pairs_evaluated": n_total * (n_total - 1) // 2 * 8,
+                "hash_and_exchange_s_rank0": timings.get("hash_and_exchange_s"), "hash_ms_max_over_ranks": hash_ms_max,
+                "allgather_ms_max_over_ranks": gather_ms_max, "sweep_ms_max_over_ranks": sweep_ms_max,
+                "allgather_bytes_per_rank": n_loc * 257, "all_pairs_evaluated": n_total * (n_total - 1) // 2 * 8,
                 "exchange": ("RCCL all-gather of 8 x 32 B per file + 1 B flags" if args.backend == "nccl" else "gloo all-gather (host staged)") if world > 1 else "none (1 GPU)",
                 "valid": ok}
 
     img_sample_dev = imgs  # kept for the CPU baseline (same images)
 
-    # ------------------------------------------------------------------ phase B: Hamming sweep
-    if "hamming" in phases:
-        n_h = int(round(args.hashes * math.sqrt(world) / (1024 * world))) * 1024 * world if args.hashes >= 1024 * world else args.hashes
+    # ------------------------------------------------------------------ phase B: Hamming sweeps
+    all_h = None
+
+    def hamming_leg(n_h, h_steps, scaling, workload):
+        """all-pairs sweep over n_h synthetic hashes living sharded over the ranks: shard generator -> one all-gather -> every rank sweeps
+        part = rank of nparts = world of the block pairs.  Returns (result dict, ok, the gathered hashes)."""
         shard = n_h // world
         n_clusters = min(1000, max(0, n_h // 5 - 1))
-        all_h = torch.empty((n_h, 32), dtype=torch.uint8, device=dev)
-        mine = all_h[rank * shard:(rank + 1) * shard]
+        hs = torch.empty((n_h, 32), dtype=torch.uint8, device=dev)
+        mine = hs[rank * shard:(rank + 1) * shard]
         cap = 1 << 20
         d_edges = torch.empty((cap, 12), dtype=torch.uint8, device=dev)
         d_count = torch.zeros(1, dtype=torch.int64, device=dev)
-        h_steps = args.hamming_steps or args.steps
         gather_ev = []
 
         def hamming_step(timed=False):
@@ -310,16 +345,16 @@ def main():
                     ea, eb = eng.event(), eng.event()
                     eng.event_record(ea, stream)
                 if args.backend == "nccl":
-                    dist.all_gather_into_tensor(all_h, mine)  # the one exchange step of the path: RCCL all-gather of hash shards
+                    dist.all_gather_into_tensor(hs, mine)  # the one exchange step of the path: RCCL all-gather of hash shards
                 else:
                     host = torch.empty((n_h, 32), dtype=torch.uint8)
                     dist.all_gather_into_tensor(host, mine.cpu())
-                    all_h.copy_(host)
+                    hs.copy_(host)
                 if timed:
                     eng.event_record(eb, stream)
                     gather_ev.append((ea, eb))
             d_count.zero_()
-            eng.hamming_all_pairs_dev(all_h.data_ptr(), n_h, args.threshold, d_edges.data_ptr(), cap, d_count.data_ptr(),
+            eng.hamming_all_pairs_dev(hs.data_ptr(), n_h, args.threshold, d_edges.data_ptr(), cap, d_count.data_ptr(),
                                       part=rank, nparts=world, stream=stream)
 
         for _ in range(max(1, min(args.warmup, 1))):
@@ -336,15 +371,14 @@ def main():
         h_step_ms = sum(eng.event_elapsed_ms(a, b) for a, b in hev) / h_steps
         gather_ms = (sum(eng.event_elapsed_ms(a, b) for a, b in gather_ev) / len(gather_ev)) if gather_ev else 0.0
         h_kernel_ms = h_step_ms - gather_ms  # the sweep (+ the shard generator, ~0.01 ms) without the exchange
+        sweep_ms_max = max_over_ranks(h_kernel_ms)
+        gather_ms_max = max_over_ranks(gather_ms)
         n_pairs = n_h * (n_h - 1) // 2
         gpairs = n_pairs * h_steps / h_elapsed / 1e9
         n_edges_local = int(d_count.item())
         n_edges = sum_over_ranks(n_edges_local)
         expected_edges = n_clusters * 10 + (1 if n_h >= 10 else 0)
         h_ok = n_edges_local <= cap and (args.threshold != 32 or n_edges == expected_edges)
-        if not h_ok:
-            valid = False
-            problems.append(f"hamming: {n_edges} edges found, {expected_edges} expected (local {n_edges_local}, cap {cap})")
         pw = eng.L.rph_hamming_prefix_dwords(args.threshold, args.hamming_kernel)  # prefix dwords the fast path examines
         pairs_per_s_rank = (n_pairs / world) / (h_kernel_ms * 1e-3)
         hbm = {"hbm_bytes_per_pair": HAMMING_HBM_BYTES_PER_PAIR,
@@ -373,13 +407,35 @@ def main():
                       "kernel_ms": h_kernel_ms, "kernel": "hamming_sweep_kernel",
                       "note": "v_bcnt_u32_b32 is a half-rate op on gfx950 (tools/valu_rate.hip): the xor+bcnt bound is 6 clk per dword per wave"}
         h_roof.update(hbm)
-        result["hamming"] = {"metric": "hamming256_pair_comparisons_per_sec", "value": gpairs, "unit": "Gpairs/s",
-                             "n_hashes": n_h, "threshold": args.threshold, "steps": h_steps, "ms_per_step": h_elapsed / h_steps * 1e3,
-                             "scaling": "weak (pairs per GPU fixed: n = 1M*sqrt(N))", "edges_found": n_edges, "edges_expected": expected_edges,
-                             "edge_capacity": cap, "valid": h_ok,
-                             "exchange": "RCCL all-gather of hash shards" if world > 1 else "none (1 GPU)",
-                             "allgather_ms": gather_ms, "allgather_bytes_per_rank": shard * 32,
-                             "roofline": h_roof}
+        out = {"metric": "hamming256_pair_comparisons_per_sec", "value": gpairs, "unit": "Gpairs/s", "workload": workload,
+               "n_hashes": n_h, "threshold": args.threshold, "steps": h_steps, "ms_per_step": h_elapsed / h_steps * 1e3,
+               "scaling": scaling, "edges_found": n_edges, "edges_expected": expected_edges,
+               "edge_capacity": cap, "valid": h_ok, "ranks_in_collective": dist.get_world_size() if dist is not None else 1,
+               "exchange": "RCCL all-gather of hash shards" if world > 1 else "none (1 GPU)",
+               "allgather_ms": gather_ms, "allgather_ms_max_over_ranks": gather_ms_max, "allgather_bytes_per_rank": shard * 32,
+               "sweep_ms_rank0": h_kernel_ms, "sweep_ms_max_over_ranks": sweep_ms_max,
+               "roofline": h_roof}
+        if not h_ok:
+            out["problem"] = f"{n_edges} edges found, {expected_edges} expected (local {n_edges_local}, cap {cap})"
+        return out, h_ok, hs
+
+    if "hamming" in phases:
+        n_h = int(round(args.hashes * math.sqrt(world) / (1024 * world))) * 1024 * world if args.hashes >= 1024 * world else args.hashes
+        result["hamming"], h_ok, all_h = hamming_leg(n_h, args.hamming_steps or args.steps, "weak (pairs per GPU fixed: n = 1M*sqrt(N))",
+                                                     f"all pairs of {n_h} synthetic 256-bit hashes, threshold {args.threshold} (BASELINE config 3 at N = 1)")
+        if not h_ok:
+            valid = False
+            problems.append("hamming: " + result["hamming"]["problem"])
+    if "hamming_10m" in phases:
+        n_s = (args.hashes_strong // (1024 * world)) * 1024 * world if args.hashes_strong >= 1024 * world else args.hashes_strong
+        result["hamming_10m"], s_ok, hs10 = hamming_leg(n_s, max(1, args.strong_steps), "strong (total fixed: the hashes split over the ranks)",
+                                                     f"all pairs of {n_s} pre-computed 256-bit hashes over {world} GPU(s), threshold {args.threshold} (BASELINE config 5)")
+        result["hamming_10m"]["is_baseline_config_5_size"] = n_s >= 9_990_000
+        if not s_ok:
+            valid = False
+            problems.append("hamming_10m: " + result["hamming_10m"]["problem"])
+        del hs10
+        torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if want_cpu:
@@ -399,15 +455,15 @@ def main():
                 host = first[:m] if done == 0 else img_sample_dev[done:done + m].cpu().numpy().reshape(-1, 512, 512, 3)
                 s, cpu_hashes, _ = oracle.bench_pdq(host, cores)
                 secs += s
-                if done == 0 and pdq_sample is not None:
-                    parity = bool(np.array_equal(cpu_hashes[:64], pdq_sample[:min(m, 64)]))
+                if pdq_sample is not None:  # ALL hashes of the CPU sample against the GPU's, bit for bit
+                    parity = parity and bool(np.array_equal(cpu_hashes[:m], pdq_sample[done:done + m]))
                 done += m
             if not parity:
                 valid = False
                 problems.append("pdq: GPU hashes differ from the CPU oracle on the sample")
             result["cpu_baseline"] = {"value": n_cpu / secs, "unit": "hashes/s", "cores": cores, "kind": "port",
                                       "sample": f"{n_cpu} of the same synthetic 512x512 RGB8 images, C oracle, {cores} threads ({secs:.1f} s)",
-                                      "host": inv, "gpu_hashes_equal_cpu_hashes_on_sample": parity}
+                                      "host": inv, "gpu_hashes_equal_cpu_hashes_on_sample": parity, "hashes_compared": n_cpu}
         if "hamming" in phases:
             # Hamming: brute-force XOR-popcount on a 64k subset (apples to apples), and the reference's own
             # algorithm (MIH find_groups) on a timed query sample of the full 1M set
@@ -424,7 +480,7 @@ def main():
                                     "extrapolated_s_for_all_queries": n_h / q_rate,
                                     "sample": f"MIHIndex::new on all {n_h} hashes + the first {q_pilot} queries of find_groups "
                                               f"(max_dist {args.threshold}), {cores} threads"}}
-    del imgs, img_sample_dev
+    del imgs, img_sample_dev, imgs_all
     torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ JPEG files -> hashes (row N3; rank 0, N = 1)

@@ -116,6 +116,11 @@ struct rph_multi {
     std::vector<ncclComm_t> comm;
     Rccl rccl;
     std::mutex mu;  // one multi-device operation at a time (they share the communicator)
+    // A device id listed more than once: several contexts ("ranks") on one GPU.  RCCL refuses two ranks on one device, so the exchange step
+    // is then carried by device-to-device copies with the collective's semantics -- everything around it (shard ranges, padding of unequal
+    // shards, compaction, the part / nparts shares of the sweep, one host thread per rank) runs as on a node.  For rehearsals and tests on
+    // a one-GPU box; a node lists every device once and takes the RCCL path.
+    bool rehearsal = false;
 };
 
 namespace {
@@ -144,12 +149,26 @@ int all_gather_rows(rph_multi *m, const std::vector<const void *> &d_local, uint
             RPH_HIP_CHECK(hipMemcpyAsync(send[i].p, d_local[i], (hi[i] - lo[i]) * width, hipMemcpyDeviceToDevice, m->ctx[i]->stream));
         }
     }
-    RPH_NCCL_CHECK(m, m->rccl.GroupStart());
-    for (int i = 0; i < world; i++) {
-        RPH_HIP_CHECK(hipSetDevice(m->devices[i]));
-        RPH_NCCL_CHECK(m, m->rccl.AllGather(even ? d_local[i] : send[i].p, even ? d_all[i].p : recv[i].p, big * width, ncclUint8, m->comm[i], m->ctx[i]->stream));
+    if (m->rehearsal) {
+        // ncclAllGather's contract with copies: rank i receives rank r's `big * width` bytes at offset r * big * width
+        for (int i = 0; i < world; i++) {  // every rank's send buffer is complete before anybody reads it
+            RPH_HIP_CHECK(hipSetDevice(m->devices[i]));
+            RPH_HIP_CHECK(hipStreamSynchronize(m->ctx[i]->stream));
+        }
+        for (int i = 0; i < world; i++) {
+            RPH_HIP_CHECK(hipSetDevice(m->devices[i]));
+            for (int r = 0; r < world; r++)
+                RPH_HIP_CHECK(hipMemcpyAsync((even ? d_all[i].as<uint8_t>() : recv[i].as<uint8_t>()) + (uint64_t)r * big * width, even ? d_local[r] : send[r].p, big * width,
+                                             hipMemcpyDeviceToDevice, m->ctx[i]->stream));
+        }
+    } else {
+        RPH_NCCL_CHECK(m, m->rccl.GroupStart());
+        for (int i = 0; i < world; i++) {
+            RPH_HIP_CHECK(hipSetDevice(m->devices[i]));
+            RPH_NCCL_CHECK(m, m->rccl.AllGather(even ? d_local[i] : send[i].p, even ? d_all[i].p : recv[i].p, big * width, ncclUint8, m->comm[i], m->ctx[i]->stream));
+        }
+        RPH_NCCL_CHECK(m, m->rccl.GroupEnd());
     }
-    RPH_NCCL_CHECK(m, m->rccl.GroupEnd());
     if (!even)
         for (int i = 0; i < world; i++) {
             RPH_HIP_CHECK(hipSetDevice(m->devices[i]));
@@ -231,6 +250,12 @@ int rph_multi_init(const int *devices, int n_devices, rph_multi **out)
             const int rc = rph_init(m->devices[i], &c);
             if (rc != RPH_OK) return fail(rc);
             m->ctx.push_back(c);
+        }
+        for (int i = 0; i < n_devices; i++)
+            for (int j = 0; j < i; j++) m->rehearsal = m->rehearsal || m->devices[i] == m->devices[j];
+        if (m->rehearsal) {  // several ranks on one GPU: no communicator (see struct rph_multi)
+            *out = m.release();
+            return RPH_OK;
         }
         int rc = load_rccl(m->rccl);
         if (rc != RPH_OK) return fail(rc);

@@ -276,6 +276,7 @@ __global__ void __launch_bounds__(256) resize_fused_kernel(const uint8_t *__rest
 typedef int rz_v4i __attribute__((ext_vector_type(4)));
 typedef int rz_v16i __attribute__((ext_vector_type(16)));
 typedef unsigned int rz_v4u __attribute__((ext_vector_type(4)));
+constexpr int RZ_KG = 6;  // K steps per group of loads
 
 // bits [lo, hi) of a 16-slot group as 16 bytes of 0 / 1
 __device__ __forceinline__ rz_v4i band16(int lo, int hi)
@@ -326,6 +327,41 @@ __global__ void __launch_bounds__(64) resize_mfma_kernel(const uint8_t *__restri
     const uint32_t rr = min(r0 + (uint32_t)n, nh - 1u);
     const int ys = (int)ay.start[rr] - y_lo, ye = ys + (r0 + (uint32_t)n < nh ? (int)ay.size[rr] : 0);
 
+    rz_v4i bx0[2][RZ_KG];  // band matrices of K steps 0 .. RZ_KG - 1
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int u = 0; u < RZ_KG; u++) bx0[cb][u] = band16(xs[cb] - 32 * u, xe[cb] - 32 * u);
+    const bool unaligned = (mis | (uint32_t)(row_stride & 3)) != 0;  // rows on dword boundaries: the 16 bytes of a step are four whole dwords
+    // pass 2's per-row constants: lane n holds those of row r0 + n (read back with v_readlane: the row of a register is static)
+    const int my_cy = ay.c1[rr], my_sz = (int)ay.size[rr];
+
+    // One group of K steps: the group's loads go out together; every step multiplies into BOTH column blocks (a block whose windows the
+    // step does not meet has an all-zero band matrix there: no branch, no copies of the accumulators).
+    auto k_group = [&](int ks0, uint32_t row_off, bool row_ok, bool first, rz_v16i(&acc1)[2]) {
+        rz_v4u d4[RZ_KG];
+        uint32_t d5[RZ_KG], sh[RZ_KG];
+#pragma unroll
+        for (int u = 0; u < RZ_KG; u++) {
+            const uint32_t a = row_off + 32u * (uint32_t)(ks0 + u), al = (row_ok && ks0 + u < n_ks) ? a & ~3u : 0x80000000u;
+            sh[u] = a & 3u;
+            d4[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, al, 0, 0);
+            d5[u] = 0;
+            if (unaligned) d5[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, al + 16u, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < RZ_KG; u++) {
+            rz_v4i av;
+            av[0] = (int)(__builtin_amdgcn_alignbyte(d4[u][1], d4[u][0], sh[u]) ^ 0x80808080u);
+            av[1] = (int)(__builtin_amdgcn_alignbyte(d4[u][2], d4[u][1], sh[u]) ^ 0x80808080u);
+            av[2] = (int)(__builtin_amdgcn_alignbyte(d4[u][3], d4[u][2], sh[u]) ^ 0x80808080u);
+            av[3] = (int)(__builtin_amdgcn_alignbyte(d5[u], d4[u][3], sh[u]) ^ 0x80808080u);
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++)
+                acc1[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, first ? bx0[cb][u] : band16(xs[cb] - 32 * (ks0 + u), xe[cb] - 32 * (ks0 + u)), acc1[cb], 0, 0, 0);
+        }
+    };
+
     rz_v16i acc2[2];
 #pragma unroll
     for (int cb = 0; cb < 2; cb++) acc2[cb] = rz_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -338,21 +374,9 @@ __global__ void __launch_bounds__(64) resize_mfma_kernel(const uint8_t *__restri
         rz_v16i acc1[2];
 #pragma unroll
         for (int cb = 0; cb < 2; cb++) acc1[cb] = rz_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        k_group(0, row_off, row_ok, true, acc1);
 #pragma unroll 1
-        for (int ks = 0; ks < n_ks; ks++) {
-            const uint32_t a = row_off + 32u * (uint32_t)ks, al = row_ok ? a & ~3u : 0x80000000u, sh = a & 3u;
-            const rz_v4u d4 = __builtin_amdgcn_raw_buffer_load_b128(rs, al, 0, 0);
-            const uint32_t d5 = __builtin_amdgcn_raw_buffer_load_b32(rs, al + 16u, 0, 0);
-            rz_v4i av;
-            av[0] = (int)(__builtin_amdgcn_alignbyte(d4[1], d4[0], sh) ^ 0x80808080u);
-            av[1] = (int)(__builtin_amdgcn_alignbyte(d4[2], d4[1], sh) ^ 0x80808080u);
-            av[2] = (int)(__builtin_amdgcn_alignbyte(d4[3], d4[2], sh) ^ 0x80808080u);
-            av[3] = (int)(__builtin_amdgcn_alignbyte(d5, d4[3], sh) ^ 0x80808080u);
-#pragma unroll
-            for (int cb = 0; cb < 2; cb++) {
-                if (ks >= ks_lo[cb] && ks < ks_hi[cb]) acc1[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, band16(xs[cb] - 32 * ks, xe[cb] - 32 * ks), acc1[cb], 0, 0, 0);
-            }
-        }
+        for (int ks0 = RZ_KG; ks0 < n_ks; ks0 += RZ_KG) k_group(ks0, row_off, row_ok, false, acc1);  // (sources beyond ~2.9 x the thumbnail)
         // band matrix of the output rows over source rows yb + 8 q + 4 kh + i (slot (kh, 4 q + i))
         rz_v4i by;
         {
@@ -370,7 +394,8 @@ __global__ void __launch_bounds__(64) resize_mfma_kernel(const uint8_t *__restri
                 uint32_t d = 0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    int v = (acc1[cb][4 * q + i] * cx[cb] + c0[cb]) >> ax.precision;
+                    int v = (__mul24(acc1[cb][4 * q + i], cx[cb]) + c0[cb]) >> ax.precision;  // |sum| < 2^15, coefficient <= 2^15
+                    asm volatile("" : "+v"(v));  // (opaque between shift and clamp: ROCm 7.2 fuses them into v_ashr_pk_u8_i32 and then ORs bytes into bits 16..31 of its result as if the instruction cleared them)
                     v = v < 0 ? 0 : (v > 255 ? 255 : v);
                     d |= (uint32_t)v << (8 * i);
                 }
@@ -381,21 +406,25 @@ __global__ void __launch_bounds__(64) resize_mfma_kernel(const uint8_t *__restri
     }
     // lane l: column o0 + l; rows r0 + 8 q + i from P[4 q + i], r0 + 8 q + 4 + i from R[4 q + i]
     const uint32_t o = o0 + (uint32_t)lane;
-    uint8_t *out = dst + (size_t)img * dst_stride + o;
+    uint8_t *out = dst + (size_t)img * dst_stride + (size_t)r0 * dst_pitch + o;
     const int half_y = 1 << (ay.precision - 1);
+    int res[32];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const auto sw = __builtin_amdgcn_permlane32_swap(acc2[0][j], acc2[1][j], false, false);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const uint32_t r = r0 + 8u * (uint32_t)(j >> 2) + 4u * (uint32_t)t + (uint32_t)(j & 3);
-            if (r < nh) {  // (uniform)
-                const int cy = ay.c1[r], sz = (int)ay.size[r];
-                int v = (((int)sw[t] + 128 * sz) * cy + half_y) >> ay.precision;
-                v = v < 0 ? 0 : (v > 255 ? 255 : v);
-                if (o < nw) out[(size_t)r * dst_pitch] = (uint8_t)v;
-            }
+            const int row = 8 * (j >> 2) + 4 * t + (j & 3);
+            const int cy = __builtin_amdgcn_readlane(my_cy, row), sz = __builtin_amdgcn_readlane(my_sz, row);
+            int v = (__mul24((int)sw[t] + 128 * sz, cy) + half_y) >> ay.precision;
+            asm volatile("" : "+v"(v));
+            res[row] = v < 0 ? 0 : (v > 255 ? 255 : v);
         }
+    }
+    if (o < nw) {
+#pragma unroll
+        for (int row = 0; row < 32; row++)
+            if (r0 + (uint32_t)row < nh) out[(uint32_t)row * dst_pitch] = (uint8_t)res[row];  // (uniform)
     }
 }
 
@@ -539,7 +568,10 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
     // the thumbnail's rows start on 16-byte boundaries where the streaming hasher (pdq_stream.hip) reads them as whole dwords
     const uint32_t np = fused ? (nw + 15u) & ~15u : nw;
     const size_t full = fused ? 0 : (size_t)w * h, tmp = fused ? 0 : (size_t)nw * h, small = (size_t)np * nh;
-    uint32_t chunk = (uint32_t)std::max<size_t>(1, (fused ? (size_t)1 << 30 : (size_t)256 << 20) / (fused ? small * 4 : full));  // (fused: as many images as the hasher takes per launch)
+    // images per launch: the streaming hasher needs nothing but the thumbnails (1 GiB of them); the multi-pass hasher takes as many images
+    // as its f32 planes allow; the two-pass resize is bounded by its full-size luma planes
+    const bool stream_hasher = fused && ctx->pdq_kernel != 5 && ctx->pdq_kernel != 0 && rph_pdq_stream_supported(nullptr, nw, nh, 1, np, small);
+    uint32_t chunk = (uint32_t)std::max<size_t>(1, (fused ? (size_t)1 << 30 : (size_t)256 << 20) / (stream_hasher ? small : (fused ? small * 4 : full)));
     chunk = std::min(std::min(chunk, n), 65535u);
     const size_t need = (full + tmp + small) * chunk;
     if (ctx->rz_bytes < need) {
@@ -593,5 +625,14 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
                                     d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr, d_valid ? d_valid + first : nullptr, stream);
         if (rc != RPH_OK) return rc;
     }
+    return RPH_OK;
+}
+
+// debug / tests: the thumbnails the last pre-downsample call of this context left in its scratch (first `bytes` bytes, rows of align16(new_w))
+extern "C" int rph_debug_copy_thumbnails(rph_ctx *ctx, void *host_dst, size_t bytes)
+{
+    if (!ctx || !host_dst || bytes > ctx->rz_bytes) return RPH_ERR_INVALID_ARG;
+    RPH_HIP_CHECK(hipDeviceSynchronize());
+    RPH_HIP_CHECK(hipMemcpy(host_dst, ctx->rz_scratch, bytes, hipMemcpyDeviceToHost));
     return RPH_OK;
 }

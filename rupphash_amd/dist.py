@@ -113,8 +113,8 @@ def all_gather_rows(local_rows, n_total, dist=None, device=None):
     is_tensor = isinstance(local_rows, torch.Tensor)
     t = local_rows if is_tensor else torch.from_numpy(np.ascontiguousarray(local_rows, np.uint8))
     home = t.device
-    t = t.reshape(t.shape[0], -1)
-    width = t.shape[1]
+    width = int(np.prod(t.shape[1:])) if t.dim() > 1 else 1  # (an empty shard -- more ranks than rows -- has no elements to infer it from)
+    t = t.reshape(t.shape[0], width)
     sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
     assert t.shape[0] == sizes[rank], (t.shape, sizes, rank)
     t = _collective_tensor(t, dist, device)
@@ -268,6 +268,10 @@ def hash_and_group_device(eng, images, n_total, similarity, dist=None, variants=
     eng.pdq_hash_batch_dev(images.data_ptr(), n_local, w, h, channels, d_hash.data_ptr(), d_quality=d_q.data_ptr(),
                            d_dihedral=d_dih.data_ptr() if variants else None, stream=stream)
     low = stored_quality_lowconf(d_q)
+    if timings is not None:  # (per-stage figures cost a synchronisation each: only when asked for)
+        torch.cuda.synchronize(dev)
+        timings["hash_ms"] = (time.perf_counter() - t0) * 1e3
+        t1 = time.perf_counter()
     # ---- the one exchange step (RCCL all-gather under nccl)
     if variants:
         all_dih = all_gather_rows(d_dih.reshape(n_local, 256), n_total, dist, dev).reshape(n_total, 8, 32)
@@ -279,6 +283,8 @@ def hash_and_group_device(eng, images, n_total, similarity, dist=None, variants=
     if timings is not None:
         torch.cuda.synchronize(dev)
         timings["hash_and_exchange_s"] = time.perf_counter() - t0
+        timings["allgather_ms"] = (time.perf_counter() - t1) * 1e3
+        t2 = time.perf_counter()
     # ---- this rank's share of the block pairs; no communication
     cap = int(edge_cap)
     while True:
@@ -294,6 +300,8 @@ def hash_and_group_device(eng, images, n_total, similarity, dist=None, variants=
         if found <= cap:
             break
         cap = found + found // 8 + 1024  # rare: more edges than expected, sweep again into a buffer that fits
+    if timings is not None:
+        timings["sweep_ms"] = (time.perf_counter() - t2) * 1e3  # (d_count.item() above waited for the sweep)
     local_edges = d_edges[:found].cpu().numpy().reshape(-1).view(EDGE_DTYPE) if found else np.zeros(0, EDGE_DTYPE)
     merged = gather_edges(local_edges, dist, dst=0, device=dev)  # tiny
     info = {"n_local": n_local, "edges_local": found, "ranks_in_collective": world}

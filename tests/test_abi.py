@@ -157,3 +157,37 @@ def test_c_consumer_runs_on_gpu():
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "distance between the two images" in r.stdout
     assert "multi (1 device)" in r.stdout  # rph_multi at n_devices = 1: the same groups as rph_group_files_pdq
+
+
+def test_rust_ffi_is_generated_from_the_header_and_matches_it():
+    """rust/rph_ffi.rs (the binding the reference's Rust modules link against; uncompiled here: no Rust toolchain) is the transliteration of
+    include/rupphash.h: regenerating it gives the committed text, every declared function is in it once with the header's arity, and the
+    pointer / integer types map as the C ABI says."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    header = open(os.path.join(ROOT, "include", "rupphash.h")).read()
+    committed = open(os.path.join(ROOT, "rust", "rph_ffi.rs")).read()
+    assert gen.generate(header) == committed, "rust/rph_ffi.rs is stale: run python tools/gen_rust_ffi.py"
+    _, _, funcs = gen.parse_header(header)
+    assert sorted(f[0] for f in funcs) == declared_functions()
+    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for name, params, ret in funcs:
+        m = re.search(r"pub fn %s\((.*?)\)( -> ([^;]+))?;" % name, committed)
+        assert m, name
+        rust_params = [p for p in m.group(1).split(", ") if p]
+        c_decl = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, code, flags=re.S).group(1)
+        c_params = [] if c_decl.strip() in ("", "void") else c_decl.split(",")
+        assert len(rust_params) == len(c_params) == len(params), name
+        for (pname, rtype), cp in zip(params, c_params):
+            assert cp.count("*") + cp.count("[") == rtype.count("*"), (name, cp, rtype)   # pointer depth (an array parameter is a pointer)
+            assert ("const" in cp.split("*")[0]) == rtype.startswith("*const") or "*" not in cp, (name, cp, rtype)
+        assert (ret is None) == (m.group(3) is None)
+    # the hand-written modules only call what the binding declares
+    for mod in ("pdqhash.rs", "hamminghash.rs", "phash.rs"):
+        text = open(os.path.join(ROOT, "rust", mod)).read()
+        for called in set(re.findall(r"ffi::(rph_[a-z0-9_]+)", text)):
+            assert re.search(r"pub fn %s\(" % called, committed), (mod, called)
+        assert "/* unchanged" not in text and "/* ..." not in text  # complete files: no elided bodies

@@ -137,3 +137,12 @@ def test_world_size_2_gloo_grouping(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_world_size_8_gloo_grouping(tmp_path):
+    """the driver's N = 8 shape: eight ranks, uneven shards (301 hashes, 6 images over 8 ranks: some ranks hold one image, some none)"""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(8))

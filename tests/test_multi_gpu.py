@@ -1,24 +1,27 @@
 """The in-library multi-GPU form (rph_multi: one context per device + an RCCL communicator, include/rupphash.h) on the devices
 this box has: with one device the all-gather is a one-rank collective and the sweep takes part 0 of 1 -- the same code path as
-with eight apart from the device count -- and every result must equal the single-context entry points."""
+with eight apart from the device count -- and every result must equal the single-context entry points.
+Second form: devices = [0, 0, 0], three ranks on the one GPU (the library's rehearsal mode: RCCL refuses two ranks on one device, so
+the collective is carried by copies with ncclAllGather's contract): unequal shards padded and compacted, an empty shard, the
+part / nparts shares of the sweeps and one host thread per rank all run as they would on a node."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def multi():
+@pytest.fixture(scope="module", params=["one device", "three ranks on one device"])
+def multi(request):
     from rupphash_amd import MultiEngine
 
-    m = MultiEngine(n_devices=1)
+    m = MultiEngine(n_devices=1) if request.param == "one device" else MultiEngine(devices=[0, 0, 0])
     yield m
     m.close()
 
 
 def test_multi_context_is_a_working_engine(multi, oracle):
-    assert multi.size() == 1
-    eng = multi.engine(0)
+    assert multi.size() in (1, 3)
+    eng = multi.engine(multi.size() - 1)
     name, cus, _ = eng.device_info()
     assert "gfx950" in name and cus > 0
     h = oracle.synth_hashes(0, 3000, 3000, n_clusters=20)
