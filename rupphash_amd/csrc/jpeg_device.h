@@ -75,6 +75,7 @@ struct SegFile {           // one per segmented file of the chunk
     uint32_t first_seg, n_segs;
     uint32_t first_item;   // its walk items: first_item .. first_item + n_segs - 1
     uint32_t total_mcus;
+    uint32_t scan_bits;    // length of the scan's entropy data in bits: no position a chain hands on may lie at or behind it
 };
 struct SegState {          // one per segment
     uint32_t entry;        // bit position (from the scan's first bit) of the first MCU that begins in or behind the segment; SEG_NONE: unknown

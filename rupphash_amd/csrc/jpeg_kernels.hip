@@ -470,6 +470,10 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
                 coef[base + zz[k < 79 ? k : 79]] = (int16_t)val;
                 k++;
             }
+            if (k > 64) {  // a run or ZRL stepped past coefficient 63: the file is damaged (the host decoder's rule, jpeg_host.cpp: kk > 64)
+                bad = 1;
+                break;
+            }
             if (k >= 64) {  // next block
                 is_dc = true;
                 k = 0;
@@ -908,7 +912,7 @@ __global__ void __launch_bounds__(64) jpeg_sync_kernel(const uint8_t *__restrict
         outs[u].v[wr] = own;  // unless decoded again below
         if (e == SEG_NONE) return;  // the predecessor has nothing to say yet
         st.entry = e;
-        if (e >= hi) {  // no MCU begins in this segment: pass the position on
+        if (e >= hi || e >= end_bits) {  // no MCU begins in this segment (or, in a damaged stream, the predecessor ran past the end of the scan: nothing is decoded from there): pass the position on
             st.from = e;
             outs[u].v[wr] = e;
             segs[u] = st;
@@ -923,7 +927,7 @@ __global__ void __launch_bounds__(64) jpeg_sync_kernel(const uint8_t *__restrict
         st.count = 0;
         st.dc[0] = st.dc[1] = st.dc[2] = 0;
         st.out_check = st.entry;
-        if (st.entry == SEG_NONE || st.entry >= hi) {
+        if (st.entry == SEG_NONE || st.entry >= hi || st.entry >= end_bits) {
             segs[u] = st;
             return;
         }
@@ -1011,6 +1015,7 @@ __global__ void __launch_bounds__(64) jpeg_sync_kernel(const uint8_t *__restrict
         } else {
             k += r + 1;
         }
+        if (mode == 2 && k > 64) break;  // the count pass decodes from verified positions: a run past coefficient 63 there is a damaged file (out stays SEG_NONE, the chain fails, and the whole-file walk reports it like the host decoder); speculative decodes of the earlier rounds start anywhere and may see this before they fall into step
         if (k >= 64) {  // next block
             is_dc = true;
             k = 0;
@@ -1067,14 +1072,16 @@ __global__ void __launch_bounds__(64) jpeg_seg_items_kernel(const SegFile *__res
         const uint32_t seg_first = running;
         uint32_t cnt = 0;
         if (st.entry != (t == 0 ? 0u : prev_out) || st.entry == SEG_NONE || out == SEG_NONE || st.out_check != out) ok = false;
+        const bool behind = st.entry != SEG_NONE && st.entry >= F.scan_bits;  // (a damaged stream: a decode ran past the end of the scan)
+        if (behind && st.count != 0) ok = false;                              // no item may start behind the scan's last byte
         if (ok) {
             cnt = st.count < F.total_mcus - running ? st.count : F.total_mcus - running;  // (behind the last MCU a decode sees padding)
             running += cnt;
         }
         HItem it;
         it.image = F.image, it.scan = 0, it.mcu_first = seg_first, it.mcu_count = cnt;
-        it.stream_off = st.entry == SEG_NONE ? 0 : st.entry >> 3;
-        it.bit_skip = st.entry == SEG_NONE ? 0 : st.entry & 7;
+        it.stream_off = (st.entry == SEG_NONE || behind) ? 0 : st.entry >> 3;
+        it.bit_skip = (st.entry == SEG_NONE || behind) ? 0 : st.entry & 7;
         it.dc[0] = dc0, it.dc[1] = dc1, it.dc[2] = dc2;
         items[F.first_item + t] = it;
         dc0 += st.dc[0], dc1 += st.dc[1], dc2 += st.dc[2];

@@ -793,6 +793,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                     sf.n_segs = (sp0.stream_len + ctx->jpeg_seg_bytes - 1) / ctx->jpeg_seg_bytes;
                     sf.first_item = 0;  // set below, behind the host's items
                     sf.total_mcus = sp0.ns == 1 ? f.comp[sp0.ci[0]].real_bw * f.comp[sp0.ci[0]].real_bh : f.mcus_x * f.mcus_y;
+                    sf.scan_bits = sp0.stream_len * 8;
                     n_segs += sf.n_segs;
                     seg_files.push_back(sf);
                     continue;

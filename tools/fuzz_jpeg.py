@@ -1,7 +1,7 @@
 """Differential fuzz of the JPEG path: the same random files through rph_jpeg_pdq_hash_batch with the Huffman streams decoded by the
 host threads and by the device walk (one file per lane) must give the same bytes (hash, quality bit pattern, 256 coefficients), in both
-arithmetic flavours; files with random damage inside their entropy segments must never hang or fault either path (their results are
-unspecified).  Files: random sizes 1..700 px, gray and colour, 4:4:4 / 4:2:2 / 4:2:0 from Pillow (baseline and progressive, optimised
+arithmetic flavours; files with random damage inside their entropy segments, and truncated files, must never hang or fault either path -- nor the
+segment synchronisation (rph_jpeg_set_segments(0, 64) / (0, 1024)) -- their results are unspecified.  Files: random sizes 1..700 px, gray and colour, 4:4:4 / 4:2:2 / 4:2:0 from Pillow (baseline and progressive, optimised
 tables, restart intervals), 4:4:0 / one scan per component / 16-bit tables from tests/jpeg_util.encode_baseline, progressive files with
 scan scripts of their own from tests/jpeg_util.encode_progressive, content from smooth to
 pure noise (long Huffman codes, ZRLs)."""
@@ -90,6 +90,20 @@ while time.time() < t_end:
             eng.jpeg_set_entropy(mode)
             out = eng.jpeg_pdq_hash_batch(bad, flavour=flavour, threads=8)
             assert out["hash"].shape == (len(bad), 32)
+        # the same damaged files, and truncated ones, with their streams cut into segments that synchronise on the device (a chain that runs
+        # past the end of a scan must neither be trusted nor read behind the stream); then the defaults again
+        trunc = []
+        for f in files[80:120]:
+            sos = f.find(b"\xff\xda")
+            if sos >= 0 and len(f) - sos > 60:
+                trunc.append(f[: sos + 14 + int(rng.integers(1, len(f) - sos - 14))])
+        for seg_bytes in (64, 1024):
+            eng.jpeg_set_segments(0, seg_bytes)
+            eng.jpeg_set_entropy(1)
+            out = eng.jpeg_pdq_hash_batch(bad + trunc, flavour=flavour, threads=8)
+            assert out["hash"].shape == (len(bad) + len(trunc), 32)
+        eng.jpeg_set_segments()
+        damaged_total += 2 * len(trunc)
     files_total += len(files)
     damaged_total += len(bad)
     rounds += 1

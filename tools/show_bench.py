@@ -16,6 +16,10 @@ for path in sys.argv[1:]:
         h = d["hamming"]
         parts.append(f"hamming thr {h['threshold']} {h['value']:.0f} Gpairs/s frac {h['roofline']['frac']:.3f} ({h['roofline']['kernel_ms']:.2f} ms, "
                      f"PW {h['roofline']['prefix_dwords']}, edges {h['edges_found']}/{h['edges_expected']}, allgather {h['allgather_ms']:.2f} ms)")
+    if "hamming_10m" in d:
+        h = d["hamming_10m"]
+        parts.append(f"config 5: {h['n_hashes']} hashes {h['value']:.0f} Gpairs/s ({h['ms_per_step']:.0f} ms per sweep, sweep max {h['sweep_ms_max_over_ranks']:.0f} ms, "
+                     f"allgather {h['allgather_ms_max_over_ranks']:.2f} ms, {h['ranks_in_collective']} rank(s), edges {h['edges_found']}/{h['edges_expected']})")
     if "jpeg" in d and "device_entropy" in d["jpeg"]:
         j = d["jpeg"]
         parts.append(f"jpeg {j['device_entropy']['files_per_s'] / 1e3:.0f} k files/s device entropy, {j['host_entropy']['files_per_s'] / 1e3:.1f} k host entropy, "
