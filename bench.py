@@ -427,10 +427,10 @@ def main():
             valid = False
             problems.append("hamming: " + result["hamming"]["problem"])
     if "hamming_10m" in phases:
-        n_s = (args.hashes_strong // (1024 * world)) * 1024 * world if args.hashes_strong >= 1024 * world else args.hashes_strong
+        n_s = (args.hashes_strong // world) * world  # equal shards for the collective (10 000 000 divides by 1, 2, 4 and 8)
         result["hamming_10m"], s_ok, hs10 = hamming_leg(n_s, max(1, args.strong_steps), "strong (total fixed: the hashes split over the ranks)",
                                                      f"all pairs of {n_s} pre-computed 256-bit hashes over {world} GPU(s), threshold {args.threshold} (BASELINE config 5)")
-        result["hamming_10m"]["is_baseline_config_5_size"] = n_s >= 9_990_000
+        result["hamming_10m"]["is_baseline_config_5_size"] = n_s == 10_000_000
         if not s_ok:
             valid = False
             problems.append("hamming_10m: " + result["hamming_10m"]["problem"])

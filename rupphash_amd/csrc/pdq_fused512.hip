@@ -38,7 +38,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 //             line is requested by two tiles (L2->fabric traffic 1.30 x algorithmic, profiles/r01_pmc_summary.txt)
 //   SW = 128: 4 strips, tile 64x128 built as two 32-row halves, 26.1 KB LDS -> 6 waves per CU; a strip row is 384 B =
 //             exactly 3 lines, traffic 1.11 x algorithmic (the rest is the edge pre-pass)
-template <int SW_, int CH_ = 3>
+template <int SW_, int CH_ = 3, bool PARK_ = true>
 struct Geo {
     static constexpr int SW = SW_;                       // strip width in pixels
     static constexpr int CH = CH_;                       // 3 = Rgb8 input, 1 = Luma8 input (the reference borrows a Luma8 image as it is, pdqhash.rs:176)
@@ -54,7 +54,17 @@ struct Geo {
     static constexpr int OFF_XCHG = NH == 2 ? 32 * TILE_PITCH : 0;
     static constexpr int OFF_STATE = TILE_BYTES;         // 7 luma rows x 512 columns, f16 = 7168 B
     static constexpr int OFF_EDGE = OFF_STATE + 7168;    // 6 chains x 64 rows x f32 = 1536 B (rv in, edge values out, in place)
-    static constexpr int LDS_BYTES = OFF_EDGE + 1536;    // SW 64: 17920 B, SW 128: 26112 B
+    // The states of the two column recurrences that are touched only between strips -- the pass-2 column chain (sum + 8 ring values per
+    // lane, twice per band) and the six edge chains (once per band) -- wait in LDS while the strips are walked: 18 VGPRs less across the
+    // strip loop, which is what the 64-px build was short of (10 spilled VGPRs = 5.2 KB of scratch traffic per image).  The 2520 bytes
+    // still leave 8 waves per CU (8 x 20 440 B); the 128-px build has the registers and would lose a wave to them.
+#ifndef RPH_PARK_CHAINS
+#define RPH_PARK_CHAINS 1
+#endif
+    static constexpr bool PARK = RPH_PARK_CHAINS && PARK_ && SW == 64;  // (PARK_ = false: the low-latency kernel, whose waves run one band each and keep no such state)
+    static constexpr int OFF_PARK_C = OFF_EDGE + 1536;                 // [9][64] floats
+    static constexpr int OFF_PARK_E = OFF_PARK_C + (PARK ? 9 * 64 * 4 : 0);  // [9][6] floats
+    static constexpr int LDS_BYTES = OFF_PARK_E + (PARK ? 9 * 6 * 4 : 0);    // SW 64: 20440 B (17920 without the parked states), SW 128: 26112 B
     static constexpr int WAVES_PER_SIMD = 2;
     static_assert(64 * 33 * 4 <= TILE_BYTES, "sample transpose buffer must fit in the dead V tile");
     static_assert((NG - 1) * 7 * CL * 16 <= (NH == 2 ? 32 : 64) * TILE_PITCH, "exchange area must fit");
@@ -507,6 +517,12 @@ __device__ __forceinline__ void col_pass(Wave &w, int b, bool second_half)
     wave_lds_fence();
     const bool active = second_half ? (w.lane >= 31) : (w.lane < 31);
     if (active) {
+        float *park = reinterpret_cast<float *>(w.lds + G::OFF_PARK_C) + w.lane;
+        if (G::PARK) {
+            w.csum = park[0];
+#pragma unroll
+            for (int e = 0; e < 8; e++) w.cring[e] = park[64 * (e + 1)];
+        }
         const float *samp = tb + (second_half ? w.lane - 31 : w.lane + 1);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -521,6 +537,11 @@ __device__ __forceinline__ void col_pass(Wave &w, int b, bool second_half)
                 // y = 8 i + 8 entered: output row o = y - 4 = 8 i + 4, i = 8 b + u - 1; /8 for the window, /64 for the scale
                 if (e == 0) w.bnew[u] = w.csum * (0.125f * 0.015625f);
             }
+        }
+        if (G::PARK) {
+            park[0] = w.csum;
+#pragma unroll
+            for (int e = 0; e < 8; e++) park[64 * (e + 1)] = w.cring[e];
         }
     }
     wave_lds_fence();
@@ -578,6 +599,12 @@ __device__ __forceinline__ void edge_prologue(Wave &w)
             w.ecs = w.ecs + v;
             w.ering[t] = v;
         }
+        if (G::PARK) {
+            float *park = reinterpret_cast<float *>(w.lds + G::OFF_PARK_E) + w.lane;
+            park[0] = w.ecs;
+#pragma unroll
+            for (int i = 0; i < 8; i++) park[6 * (i + 1)] = w.ering[i];
+        }
     }
     wave_lds_fence();
 }
@@ -596,6 +623,12 @@ __device__ __forceinline__ void edge_band(Wave &w, int b)
     wave_lds_fence();
     if (w.lane < 6) {
         float *mine = edge + w.lane * 64;
+        float *park = reinterpret_cast<float *>(w.lds + G::OFF_PARK_E) + w.lane;
+        if (G::PARK) {
+            w.ecs = park[0];
+#pragma unroll
+            for (int i = 0; i < 8; i++) w.ering[i] = park[6 * (i + 1)];
+        }
 #pragma unroll 1
         for (int u = 0; u < 8; u++) {
             float in[8], out[8];
@@ -622,6 +655,11 @@ __device__ __forceinline__ void edge_band(Wave &w, int b)
             }
 #pragma unroll
             for (int e = 0; e < 8; e++) mine[8 * u + e] = out[e];
+        }
+        if (G::PARK) {
+            park[0] = w.ecs;
+#pragma unroll
+            for (int i = 0; i < 8; i++) park[6 * (i + 1)] = w.ering[i];
         }
     }
     wave_lds_fence();
@@ -708,6 +746,10 @@ __global__ void __launch_bounds__(64, G::WAVES_PER_SIMD) pdq_fused512_kernel(con
     for (int i = 0; i < 32; i++) w.smp[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) w.cring[i] = 0.f;
+    if (G::PARK) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) reinterpret_cast<float *>(lds + G::OFF_PARK_C)[64 * i + w.lane] = 0.f;
+    }
     rph::tail_init(w.tail);
     w.want_quality = quality != nullptr;
 #pragma unroll
@@ -737,6 +779,10 @@ __global__ void __launch_bounds__(64, G::WAVES_PER_SIMD) pdq_fused512_kernel(con
     do_band<G, 2>(w, 7, pre);
 
     // pass-2 column chain, phase 4 first step: out[508] = (csum - in[504]) / 7  (ring slot 0), unscale by 64
+    if (G::PARK) {
+        w.csum = reinterpret_cast<const float *>(lds + G::OFF_PARK_C)[w.lane];
+        w.cring[0] = reinterpret_cast<const float *>(lds + G::OFF_PARK_C)[64 + w.lane];
+    }
     w.csum = w.csum - w.cring[0];
     rph::tail_row(w.tail, (w.csum / 7.0f) * 0.015625f, 63, w.lane, w.want_quality);
 
@@ -935,7 +981,7 @@ int rph_launch_pdq_fused512_ll(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, si
     }
     for (uint32_t first = 0; first < n; first += chunk) {
         const uint32_t m = (n - first) < chunk ? (n - first) : chunk;
-        hipLaunchKernelGGL(pdq_fused512_ll_kernel<Geo<64>>, dim3(m), dim3(512), 0, stream, d_px + (size_t)first * image_stride, m, row_stride, image_stride,
+        hipLaunchKernelGGL((pdq_fused512_ll_kernel<Geo<64, 3, false>>), dim3(m), dim3(512), 0, stream, d_px + (size_t)first * image_stride, m, row_stride, image_stride,
                            sc.p, d_hash + (size_t)first * 32, d_quality ? d_quality + first : nullptr, d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr,
                            d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr, d_valid ? d_valid + first : nullptr);
         RPH_HIP_CHECK(hipGetLastError());
