@@ -92,6 +92,7 @@ def parse_args():
     ap.add_argument("--only", default="", help="comma list of phases to run: pdq, e2e, hamming (default: all)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget per cpu_baseline leg")
     ap.add_argument("--jpeg-files", type=int, default=100_000, help="files per call of the JPEG leg (SURVEY 8f row N3; rank 0 at N = 1 only)")
+    ap.add_argument("--jpeg-distinct", type=int, default=4096, help="distinct files of the JPEG leg (the first images of the synthetic sequence, repeated to --jpeg-files)")
     ap.add_argument("--no-jpeg", action="store_true", help="skip the JPEG leg")
     return ap.parse_args()
 
@@ -513,26 +514,32 @@ def main():
 
 def jpeg_leg(eng, np, args, oracle):
     """Row N3: JPEG FILES in host memory -> PDQ hashes (load_image_fast + generate_pdq_features, scanner.rs:461-508, :1410), as one call.
-    Files: the first 64 images of the synthetic sequence, JPEG-coded by Pillow (baseline, 4:2:0, quality 85: what cameras write),
+    Files: the first 4 096 images of the synthetic sequence, JPEG-coded by Pillow (baseline, 4:2:0, quality 85: what cameras write),
     repeated to --jpeg-files.  Timed around the C call (the file pointer / length arrays are what a C caller already holds); PCIe is
     inside the timed region by definition -- the files start in host memory."""
     import io
 
     from PIL import Image
 
-    distinct = 64
-    imgs = eng.synth_images(0, distinct)
-    base = []
-    for k in range(distinct):
+    from concurrent.futures import ThreadPoolExecutor
+
+    cores = cpu_inventory()["threads_used"]
+    distinct = min(args.jpeg_distinct, args.jpeg_files)
+
+    def encode(a):
         buf = io.BytesIO()
-        Image.fromarray(imgs[k]).save(buf, "JPEG", quality=85, subsampling=2)
-        base.append(buf.getvalue())
+        Image.fromarray(a).save(buf, "JPEG", quality=85, subsampling=2)
+        return buf.getvalue()
+
+    base = []
+    with ThreadPoolExecutor(max_workers=cores) as pool:  # (Pillow's encoder releases the GIL)
+        for first in range(0, distinct, 256):
+            base += list(pool.map(encode, eng.synth_images(first, min(256, distinct - first))))
     n = args.jpeg_files
     files = eng.jpeg_file_list([base[k % distinct] for k in range(n)])
     file_bytes = sum(len(base[k % distinct]) for k in range(n))
     out = {"files": n, "distinct_files": distinct, "file": "512x512 baseline JPEG, 4:2:0, quality 85 (Pillow / libjpeg-turbo encoder)",
            "mean_file_bytes": file_bytes / n, "flavour": "zune (parity unpinned against zune-jpeg; the libjpeg flavour is pinned against libjpeg-turbo)"}
-    cores = cpu_inventory()["threads_used"]
     # entropy decoding on the device: one file per lane
     eng.jpeg_set_entropy(1)
     eng.jpeg_pdq_hash_batch(files, threads=cores)  # buffers
@@ -560,43 +567,58 @@ def jpeg_leg(eng, np, args, oracle):
     # CPU: what one host thread does with the same files -- libjpeg-turbo through Pillow (SIMD; not the reference's zune-jpeg, which cannot
     # be built here) for the decode, and the C oracle for decode + hash of the distinct files (the parity check)
     t0 = time.perf_counter()
-    for f in base:
+    for f in base[:256]:
         np.asarray(Image.open(io.BytesIO(f)))
-    dec = (time.perf_counter() - t0) / distinct
+    dec = (time.perf_counter() - t0) / min(256, distinct)
     out["cpu_baseline"] = {"value": 1.0 / dec, "unit": "files/s (decode only)", "cores": 1, "kind": "third party: libjpeg-turbo via Pillow",
-                           "sample": f"{distinct} distinct files, one thread; the reference decodes with zune-jpeg 0.5.15 on every rayon worker"}
+                           "sample": f"{min(256, distinct)} distinct files, one thread; the reference decodes with zune-jpeg 0.5.15 on every rayon worker"}
     if oracle is not None:
-        for k in range(0, distinct, 8):
+        for k in range(0, distinct, max(1, distinct // 16)):
             rc, coeffs, _ = oracle.pdq_features(oracle.jpeg_decode(base[k], 0))
             ok = ok and rc == 0 and bool(np.array_equal(dev["hash"][k], oracle.to_hash(coeffs)))
         out["gpu_hashes_equal_cpu_oracle_on_sample"] = ok
-    # Photo-sized and progressive files (what collections hold): the reference's own bench image (tests/golden/bench.jpg, 1280x854), 16 crops
+    # Photo-sized and progressive files (what collections hold): the reference's own bench image (tests/golden/bench.jpg, 1280x854), 64 crops
     # re-coded baseline 4:2:0 q90 without restart markers (streams cut into segments that synchronise on the device) and as progressive files
-    # (one lane per file through all scans); > 512 px, so the pre-downsample and the multi-pass hasher follow the decode.
+    # (one lane per file through all scans); > 512 px, so the pre-downsample and the streaming hasher follow the decode.
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "bench.jpg")
     if os.path.exists(golden) and n >= 20000:
         im = Image.open(golden)
+        im.load()  # (the encoder threads below crop it: decode once, here)
         eng.jpeg_set_entropy(1)
+        def photo(args_):
+            kx, ky, kw_ = args_
+            buf = io.BytesIO()
+            im.crop((kx, ky, kx + 1265, ky + 850)).save(buf, "JPEG", quality=90, subsampling=2, **kw_)
+            return buf.getvalue()
+
         for label, kw in (("photos_baseline", {}), ("photos_progressive", {"progressive": True})):
-            variants = []
-            for k in range(16):
-                buf = io.BytesIO()
-                im.crop((k, k // 2, 1280 - (15 - k), 854 - (7 - k // 2))).save(buf, "JPEG", quality=90, subsampling=2, **kw)
-                variants.append(buf.getvalue())
-            m_ph = 8000
-            ph = eng.jpeg_file_list([variants[k % 16] for k in range(m_ph)])
+            nv = 64  # distinct crops: 16 horizontal x 4 vertical offsets
+            with ThreadPoolExecutor(max_workers=cores) as pool:
+                variants = list(pool.map(photo, [(k % 16, k // 16, kw) for k in range(nv)]))
+            m_ph = 20000 if label == "photos_baseline" else 8000
+            ph = eng.jpeg_file_list([variants[k % nv] for k in range(m_ph)])
             eng.jpeg_pdq_hash_batch(ph, threads=cores)
             t0 = time.perf_counter()
             got = eng.jpeg_pdq_hash_batch(ph, threads=cores)
             dt = time.perf_counter() - t0
             good = bool(got["valid"].all())
             if oracle is not None:
-                rc, coeffs, _ = oracle.pdq_features(oracle.jpeg_decode(variants[3], 0))
-                good = good and rc == 0 and bool(np.array_equal(got["hash"][3], oracle.to_hash(coeffs)))
+                for k in (3, 37):
+                    rc, coeffs, _ = oracle.pdq_features(oracle.jpeg_decode(variants[k], 0))
+                    good = good and rc == 0 and bool(np.array_equal(got["hash"][k], oracle.to_hash(coeffs)))
             ok = ok and good
-            out[label] = {"files_per_s": m_ph / dt, "files": m_ph, "mean_file_bytes": sum(len(v) for v in variants) / 16, "geometry": "1265x850 (crops of tests/golden/bench.jpg)",
-                          "jpeg_MB_per_s": sum(len(variants[k % 16]) for k in range(m_ph)) / dt / 1e6, "hash_equals_cpu_oracle_on_sample": good}
+            out[label] = {"files_per_s": m_ph / dt, "files": m_ph, "distinct_files": nv, "mean_file_bytes": sum(len(v) for v in variants) / nv,
+                          "geometry": "1265x850 (crops of tests/golden/bench.jpg) -> decode -> pre-downsample on the matrix pipe -> streaming hasher",
+                          "jpeg_MB_per_s": sum(len(variants[k % nv]) for k in range(m_ph)) / dt / 1e6, "pixel_GB_per_s": m_ph * 1265 * 850 * 3 / dt / 1e9,
+                          "hash_equals_cpu_oracle_on_sample": good}
         eng.jpeg_set_entropy(2)
+    # per-stage rooflines: rocprofv3 cannot run inside this process, so the figures are those of the same workloads profiled by
+    # tools/jpeg_stage_profile.sh and committed under profiles/ (kernel time per call from the trace, algorithmic bytes from the counts)
+    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("jpeg_stage_roofline.json")), reverse=True):
+        with open(os.path.join(ROOT, "profiles", cand)) as f:
+            out["stage_rooflines"] = json.load(f)
+        out["stage_rooflines"]["file"] = "profiles/" + cand
+        break
     out["valid"] = ok
     if not ok:
         out["problem"] = "device-entropy, host-entropy and oracle hashes differ"
