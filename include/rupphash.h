@@ -127,12 +127,14 @@ int rph_pdq_hashes_from_coeffs_dev(rph_ctx *ctx, const void *d_coeffs, uint32_t 
 void rph_pdq_to_hash(const float *coeffs256, uint8_t *hash32_out);
 void rph_pdq_dihedral_one(const float *coeffs256, uint8_t *out8x32);
 
-/* Which PDQ kernel a context uses for 512x512 RGB8: 0 = generic multi-pass (any geometry), 1 = fused single-pass, one wave
+/* Which PDQ kernels a context uses.  512x512 RGB8 / Luma8: 0 = generic multi-pass (any geometry), 1 = fused single-pass, one wave
  * per image, 64-px strips (8 waves per CU: the throughput kernel, ~0.3 ms per image however few there are), 2 = the same
  * with 128-px strips (cache-line aligned loads, 6 waves per CU), 3 = fused low-latency form (eight waves share an image:
- * ~60 us, one image per CU), 4 = automatic (default): 3 below 768 images per call, 1 from there, 5 = no fused kernel: the
- * multi-pass kernels every other geometry takes by default (rows through LDS tiles; 0 = their plain one-thread-per-line
- * form, which also selects the two-pass pre-downsample).  All produce identical bits.  Debug/bench. */
+ * ~60 us, one image per CU), 4 = automatic (default): 3 below 768 images per call, 1 from there.  Every other geometry of
+ * 128..512 px (thumbnails behind the pre-downsample included): the streaming single-pass kernel (one wave per image) from 384
+ * images per call, below that the multi-pass kernels (rows through LDS tiles); 6 = as 4 with the streaming kernel at every
+ * batch size (tests); 5 = no single-pass kernel at all: the multi-pass kernels (0 = their plain one-thread-per-line form,
+ * which also selects the two-pass pre-downsample).  All produce identical bits.  Debug/bench. */
 int rph_pdq_set_kernel(rph_ctx *ctx, int which);
 
 /* calculate_target_dimensions (pdqhash.rs:224-235): integer geometry, host. */

@@ -1002,7 +1002,7 @@ int rph_launch_pdq_fused512(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, size_
     }
     // 3 = the low-latency kernel, 4 (default) = automatic: below ~3 images per CU the eight-waves-per-image kernel finishes sooner
     // (~60 us against ~300 us), above it the one-wave-per-image kernel has the throughput
-    if (ctx->pdq_kernel == 3 || (ctx->pdq_kernel == 4 && n < 768))
+    if (ctx->pdq_kernel == 3 || ((ctx->pdq_kernel == 4 || ctx->pdq_kernel == 6) && n < 768))
         return rph_launch_pdq_fused512_ll(ctx, d_px, n, row_stride, image_stride, d_hash, d_quality, d_coeffs, d_dihedral, d_valid, stream);
     if (ctx->pdq_kernel == 2)
         hipLaunchKernelGGL(pdq_fused512_kernel<Geo<128>>, dim3(n), dim3(64), 0, stream, d_px, n, row_stride, image_stride, d_hash,

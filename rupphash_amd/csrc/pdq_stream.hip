@@ -82,6 +82,8 @@ struct StWave {
     // pass-2 column recurrence (lane = kept column), carried over the whole image
     float dsum, dprev[8];
     f32x32 smp;  // pass-2 row outputs at the kept columns since the last D pass
+    v4u carry[2];   // the strip's last 32 image bytes per row (two row blocks): they are the next strip's first 32
+    v4u ahead[2][2];  // an even strip also fetches the odd strip's 64 new bytes per row: a row's 128 new bytes of a strip pair in one go
     rph::TailAcc tail;
     bool want_quality;
 };
@@ -94,18 +96,35 @@ __device__ __forceinline__ void st_ab_stage(StWave &w, const __amdgpu_buffer_rsr
     float *tile = w.lds;
     float *sums = w.lds + ST_OFF_SUMS;
 
-    // image bytes: block m holds rows T0 - 8 + 32 m ..; lane (n, kh) fetches bytes [c0 - 16 + 32 c + 16 kh, + 16) of row n of the block
+    // image bytes: block m holds rows T0 - 8 + 32 m ..; lane (n, kh) fetches bytes [c0 - 16 + 32 c + 16 kh, + 16) of row n of the block.
+    // Chunk 0 of a strip is chunk 2 of the strip before it ([c0 - 16, c0 + 16) = [(c0 - 64) + 48, (c0 - 64) + 80)): it stays in registers, and an
+    // even strip fetches the 64 new bytes per row of the odd strip behind it as well: 128 new bytes per row and strip pair in one go, no byte of
+    // a band requested twice, a 128-byte line touched by at most two fetches.
     v4u ch[2][3];
 #pragma unroll
     for (int m = 0; m < 2; m++) {
         const int row = T0 - 8 + 32 * m + n;
         const int off0 = row * rs32 + c0 - 16 + 16 * kh;
+        const bool odd_strip = (c0 & 64) != 0;  // (uniform)
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
+        for (int c = 0; c < 5; c++) {  // chunks 3 and 4 are the next strip's chunks 1 and 2
+            if (c == 0 && c0 != 0) {
+                ch[m][0] = w.carry[m];
+                continue;
+            }
+            if (odd_strip) {
+                if (c == 1 || c == 2) ch[m][c] = w.ahead[m][c - 1];
+                continue;
+            }
             const int off = off0 + 32 * c;
             const uint32_t uoff = (row < 0 || row >= g.H || off < 0) ? 0x80000000u : (uint32_t)off;  // outside: the range check returns 0
-            ch[m][c] = __builtin_amdgcn_raw_buffer_load_b128(rs, uoff, 0, 0);
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, uoff, 0, 0);
+            if (c < 3)
+                ch[m][c] = v;
+            else
+                w.ahead[m][c - 3] = v;
         }
+        w.carry[m] = ch[m][2];
     }
     // band matrices of the two 32-column blocks: slot 32 ks + 16 kh + j <-> source column c0 - 16 + 32 nb + 32 ks + 16 kh + j
     v4i bm[2][2];

@@ -570,7 +570,8 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
     const size_t full = fused ? 0 : (size_t)w * h, tmp = fused ? 0 : (size_t)nw * h, small = (size_t)np * nh;
     // images per launch: the streaming hasher needs nothing but the thumbnails (1 GiB of them); the multi-pass hasher takes as many images
     // as its f32 planes allow; the two-pass resize is bounded by its full-size luma planes
-    const bool stream_hasher = fused && ctx->pdq_kernel != 5 && ctx->pdq_kernel != 0 && rph_pdq_stream_supported(nullptr, nw, nh, 1, np, small);
+    const bool stream_hasher = fused && ctx->pdq_kernel != 5 && ctx->pdq_kernel != 0 && (n >= RPH_STREAM_MIN_IMAGES || ctx->pdq_kernel == 6) &&
+                               rph_pdq_stream_supported(nullptr, nw, nh, 1, np, small);
     uint32_t chunk = (uint32_t)std::max<size_t>(1, (fused ? (size_t)1 << 30 : (size_t)256 << 20) / (stream_hasher ? small : (fused ? small * 4 : full)));
     chunk = std::min(std::min(chunk, n), 65535u);
     const size_t need = (full + tmp + small) * chunk;
@@ -610,7 +611,7 @@ int rph_launch_pdq_resized(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
         RPH_HIP_CHECK(hipGetLastError());
         // generate_pdq_from_luma on the thumbnail (no second size check in the reference: a 4000x5 input is hashed from 512x1).
         // It records scratch_done on `stream` when it is through, which also covers the planes above.
-        if (ctx->pdq_kernel != 5 && ctx->pdq_kernel != 0 && rph_pdq_stream_supported(p_small, nw, nh, 1, np, small)) {  // one streaming kernel per thumbnail
+        if (stream_hasher) {  // one streaming kernel per thumbnail
             rc = rph_launch_pdq_stream(ctx, (const uint8_t *)p_small, m, nw, nh, np, small, d_hash + (size_t)first * 32, d_quality ? d_quality + first : nullptr,
                                        d_coeffs ? d_coeffs + (size_t)first * 256 : nullptr, d_dihedral ? d_dihedral + (size_t)first * 256 : nullptr,
                                        d_valid ? d_valid + first : nullptr, stream);

@@ -315,7 +315,7 @@ int rph_hamming_set_kernel(rph_ctx *ctx, int which)
 
 int rph_pdq_set_kernel(rph_ctx *ctx, int which)
 {
-    if (!ctx || which < 0 || which > 5) return RPH_ERR_INVALID_ARG;
+    if (!ctx || which < 0 || which > 6) return RPH_ERR_INVALID_ARG;
     ctx->pdq_kernel = which;
     return RPH_OK;
 }
@@ -354,12 +354,15 @@ int rph_pdq_hash_batch_dev(rph_ctx *ctx, const void *d_px, uint32_t n, uint32_t 
                                          (float *)d_quality, (float *)d_coeffs, (uint8_t *)d_dihedral, (uint8_t *)d_valid, s, channels);
         if (rc != RPH_ERR_UNSUPPORTED) return rc;
     }
-    // every other Luma8 geometry from 128 x 128: the streaming single-pass kernel (pdq_stream.hip)
-    if (ctx->pdq_kernel >= 1 && ctx->pdq_kernel != 5 && rph_pdq_stream_supported((const uint8_t *)d_px, w, h, channels, row_stride, image_stride)) {
+    // every other Luma8 geometry from 128 x 128: the streaming single-pass kernel (pdq_stream.hip) -- one wave per image, ~0.4 ms from an
+    // image's first byte to its hash however few there are, so calls of a few images (the one-image-per-call queue) keep the multi-pass
+    // kernels, which spread an image over the chip (~0.15 ms)
+    const bool stream_ok = ctx->pdq_kernel >= 1 && ctx->pdq_kernel != 5 && (n >= RPH_STREAM_MIN_IMAGES || ctx->pdq_kernel == 6);
+    if (stream_ok && rph_pdq_stream_supported((const uint8_t *)d_px, w, h, channels, row_stride, image_stride)) {
         return rph_launch_pdq_stream(ctx, (const uint8_t *)d_px, n, w, h, row_stride, image_stride, (uint8_t *)d_hash32, (float *)d_quality, (float *)d_coeffs,
                                      (uint8_t *)d_dihedral, (uint8_t *)d_valid, s);
     }
-    if (ctx->pdq_kernel >= 1 && ctx->pdq_kernel != 5 && rph_pdq_stream_color_supported((const uint8_t *)d_px, w, h, channels, row_stride, image_stride))
+    if (stream_ok && rph_pdq_stream_color_supported((const uint8_t *)d_px, w, h, channels, row_stride, image_stride))
         return rph_launch_pdq_stream_color(ctx, (const uint8_t *)d_px, n, w, h, channels, row_stride, image_stride, (uint8_t *)d_hash32, (float *)d_quality,
                                            (float *)d_coeffs, (uint8_t *)d_dihedral, (uint8_t *)d_valid, s);
     return rph_launch_pdq_generic(ctx, (const uint8_t *)d_px, n, w, h, channels, row_stride, image_stride, (uint8_t *)d_hash32,

@@ -91,7 +91,9 @@ int rph_launch_pdq_generic(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32
 int rph_launch_pdq_fused512(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, size_t row_stride, size_t image_stride,
                             uint8_t *d_hash, float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid,
                             hipStream_t stream, uint32_t channels = 3);  // channels: 3 (Rgb8) or 1 (Luma8)
-// pdq_stream.hip: one streaming kernel for Luma8 images of 128..512 x 128..512 with dword-aligned rows
+// pdq_stream.hip: one streaming kernel for Luma8 images of 128..512 x 128..512 with dword-aligned rows; automatic mode takes it from
+// RPH_STREAM_MIN_IMAGES images per call (below that a wave per image leaves the chip empty and the image waits ~0.4 ms for its one wave)
+constexpr uint32_t RPH_STREAM_MIN_IMAGES = 384;
 bool rph_pdq_stream_supported(const uint8_t *d_px, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride, size_t image_stride);
 int rph_launch_pdq_stream(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride, uint8_t *d_hash,
                           float *d_quality, float *d_coeffs, uint8_t *d_dihedral, uint8_t *d_valid, hipStream_t stream);

@@ -59,11 +59,11 @@ GEOMS = [(512, 512, 3), (5, 5, 3), (64, 64, 1), (100, 37, 3), (512, 300, 4), (33
          (129, 65, 3)]
 
 
-@pytest.mark.parametrize("which", [0, 4])
+@pytest.mark.parametrize("which", [0, 4, 6])
 @pytest.mark.parametrize("w,h,ch", GEOMS)
 def test_pdq_generic_kernel_matches_oracle(eng, oracle, w, h, ch, which):
-    """which = 0: the plain multi-pass kernels (one thread per line); 4: the default (512x512 fused; elsewhere rows through LDS tiles, the second
-    half of the filter on the 64 kept columns only)"""
+    """which = 0: the plain multi-pass kernels (one thread per line); 4: the default (512x512 fused; elsewhere, for calls this small, rows through
+    LDS tiles, the second half of the filter on the 64 kept columns only); 6: the streaming single-pass kernel wherever it applies"""
     rng = np.random.default_rng(w * 1000 + h + ch)
     n = 3
     if ch == 1:
@@ -121,7 +121,7 @@ RESIZED = [(780, 768, 3), (1280, 854, 3), (513, 512, 3), (512, 513, 1), (4000, 5
            (2048, 1536, 3)]
 
 
-@pytest.mark.parametrize("which", [0, 4])
+@pytest.mark.parametrize("which", [0, 4, 6])
 @pytest.mark.parametrize("w,h,ch", RESIZED)
 def test_pdq_with_predownsample_matches_oracle(eng, oracle, w, h, ch, which):
     """pdqhash.rs:181-220: sides > 512 px go through luma -> box-convolution thumbnail -> PDQ.  GPU == oracle bit for bit
@@ -137,7 +137,7 @@ def test_pdq_with_predownsample_matches_oracle(eng, oracle, w, h, ch, which):
     else:
         imgs[0, ..., 0] = grad
         imgs[0, ..., 1] = grad[::-1]
-    eng.set_pdq_kernel(which)  # 0: luma plane + two resize kernels + plain hasher; 4: both resize passes in one kernel, tiled hasher
+    eng.set_pdq_kernel(which)  # 0: luma plane + two resize kernels + plain hasher; 4: both resize passes in one kernel (on the matrix pipe for Luma8), tiled hasher; 6: streaming hasher
     out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
     eng.set_pdq_kernel(4)
     for k in range(n):
@@ -168,10 +168,12 @@ def test_predownsample_odd_and_very_large_geometries(eng, oracle, w, h, ch):
     else:
         imgs[0, ..., 1] = grad
     outs = []
-    for which in (0, 4):
+    for which in (0, 4, 6):
         eng.set_pdq_kernel(which)
         outs.append(eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True))
     eng.set_pdq_kernel(4)
+    assert np.array_equal(outs[2]["hash"], outs[1]["hash"]) and np.array_equal(outs[2]["coeffs"].view(np.uint32), outs[1]["coeffs"].view(np.uint32))
+    assert np.array_equal(outs[2]["quality"].view(np.uint32), outs[1]["quality"].view(np.uint32)) and np.array_equal(outs[2]["dihedral"], outs[1]["dihedral"])
     assert np.array_equal(outs[0]["valid"], outs[1]["valid"]) and outs[1]["valid"].all()
     assert np.array_equal(outs[0]["hash"], outs[1]["hash"]) and np.array_equal(outs[0]["dihedral"], outs[1]["dihedral"])
     assert np.array_equal(outs[0]["coeffs"].view(np.uint32), outs[1]["coeffs"].view(np.uint32))

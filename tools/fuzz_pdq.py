@@ -1,5 +1,6 @@
 """Differential fuzz of the PDQ kernels: the two fused geometries and the generic multi-pass kernel must agree bit for bit
-(hash, quality, coefficients, dihedral hashes) on random 512x512 RGB images of many content classes."""
+(hash, quality, coefficients, dihedral hashes) on random 512x512 RGB images of many content classes; and the streaming single-pass
+kernel (pdq_stream.hip) with the multi-pass kernels on Luma8 / Rgb8 crops of the same content at random geometries 128..512."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -53,5 +54,22 @@ while time.time() - t0 < budget:
         assert np.array_equal(outs[0]["coeffs"].view(np.uint32), other["coeffs"].view(np.uint32))
         assert np.array_equal(outs[0]["quality"].view(np.uint32), other["quality"].view(np.uint32))
     total += len(batch)
+    # the streaming kernel against the multi-pass kernels: crops at a random geometry, gray (rows padded to whole dwords when the width is a
+    # multiple of four: packed rows of other widths take the multi-pass kernels in every mode) and colour
+    w, h = int(rng.integers(128, 513)), int(rng.integers(128, 513))
+    if rng.random() < 0.6:
+        w &= ~3
+    crops = np.ascontiguousarray(batch[:16, :h, :w, :])
+    for imgs in (np.ascontiguousarray(crops[..., 1]), crops):
+        res = []
+        for kern in (0, 5, 6):
+            eng.set_pdq_kernel(kern)
+            res.append(eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True))
+        for other in res[1:]:
+            for k in ("hash", "valid", "dihedral"):
+                assert np.array_equal(res[0][k], other[k]), (k, w, h, imgs.shape)
+            assert np.array_equal(res[0]["coeffs"].view(np.uint32), other["coeffs"].view(np.uint32)), (w, h, imgs.shape)
+            assert np.array_equal(res[0]["quality"].view(np.uint32), other["quality"].view(np.uint32)), (w, h, imgs.shape)
+        total += len(imgs)
 eng.set_pdq_kernel(4)
-print(f"seed {seed}: {total} images, fused strip64 == fused strip128 == fused low-latency == generic (plain and tiled), bit for bit")
+print(f"seed {seed}: {total} images, fused strip64 == fused strip128 == fused low-latency == generic (plain and tiled); streaming == multi-pass at random geometries, bit for bit")
