@@ -104,4 +104,4 @@ int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HIm
 // kernel, which writes the files' walk items (d_items[first_item ..]) -- n_segs of them per file, or one whole-file item and empty ones
 // when the file's chain did not verify.  d_bitmap: seg_bytes + 12 bytes per segment (marks, two `out` slots, the segment -> file map).
 int rph_jpeg_launch_segments(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const SegFile *d_files, uint32_t n_files, SegState *d_segs,
-                             uint32_t n_segs, uint32_t seg_bytes, uint32_t *d_bitmap, int rounds, const rphj::DeviceLut *d_luts, HItem *d_items);
+                             uint32_t n_segs, uint32_t seg_bytes, uint32_t *d_bitmap, int rounds, const rphj::DeviceLut *d_luts, uint32_t n_luts, HItem *d_items);

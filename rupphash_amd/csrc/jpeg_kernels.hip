@@ -888,51 +888,77 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
 struct SegOut2 {
     uint32_t v[2];
 };
-__global__ void __launch_bounds__(64) jpeg_sync_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const SegFile *__restrict__ files,
+// LDS_TABLES as in the walk: the table probe is on the critical path of every symbol (from global memory it is a cache round trip per symbol:
+// 68 % of this kernel's wave-cycles were spent waiting, profiles/r03_pmc_jpeg_walk_sync.txt).
+constexpr int SYNC_BLOCK = 256;
+template <int LDS_TABLES>
+__global__ void __launch_bounds__(SYNC_BLOCK) jpeg_sync_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const SegFile *__restrict__ files,
                                                        const uint32_t *__restrict__ seg_file, SegState *__restrict__ segs, SegOut2 *__restrict__ outs, uint32_t n_segs,
-                                                       uint32_t seg_bytes, uint32_t *__restrict__ bitmap, int mode, int round, const rphj::DeviceLut *__restrict__ luts)
+                                                       uint32_t seg_bytes, uint32_t *__restrict__ bitmap, int mode, int round, const rphj::DeviceLut *__restrict__ g_luts,
+                                                       uint32_t n_luts)
 {
-    const uint32_t u = blockIdx.x * 64 + threadIdx.x;
-    if (u >= n_segs) return;
-    const SegFile F = files[seg_file[u]];
-    const uint32_t t = u - F.first_seg;
+    __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
+    const rphj::DeviceLut *luts = LDS_TABLES > 0 ? s_luts : g_luts;
+    const uint32_t u = blockIdx.x * SYNC_BLOCK + threadIdx.x;
+    // what this lane has to do is decided first: in the validation rounds and in the count pass most lanes have nothing to decode, and a
+    // workgroup none of whose lanes decodes leaves without copying the tables
+    SegFile F = files[seg_file[u < n_segs ? u : n_segs - 1]];
+    const uint32_t t = (u < n_segs ? u : n_segs - 1) - F.first_seg;
     const HImage *im = imgs + F.image;
     const HScan *S = &im->scan[0];
     const uint32_t seg_bits = seg_bytes * 8, lo = t * seg_bits, hi = lo + seg_bits, end_bits = S->len * 8;
-    uint32_t *bm = bitmap + (size_t)u * (seg_bytes / 4);
-    SegState st = segs[u];
+    uint32_t *bm = bitmap + (size_t)(u < n_segs ? u : n_segs - 1) * (seg_bytes / 4);
+    SegState st{};
     const int rd = (round + 1) & 1, wr = round & 1;  // validation round r reads the outs of round r - 1 (round 0 wrote slot 0)
-    uint32_t start;
-    if (mode == 0) {
-        start = lo;
-        st.entry = t == 0 ? 0 : SEG_NONE;
-    } else if (mode == 1) {
-        const uint32_t own = outs[u].v[rd];
-        const uint32_t e = t == 0 ? 0 : outs[u - 1].v[rd];
-        outs[u].v[wr] = own;  // unless decoded again below
-        if (e == SEG_NONE) return;  // the predecessor has nothing to say yet
-        st.entry = e;
-        if (e >= hi || e >= end_bits) {  // no MCU begins in this segment (or, in a damaged stream, the predecessor ran past the end of the scan: nothing is decoded from there): pass the position on
-            st.from = e;
-            outs[u].v[wr] = e;
-            segs[u] = st;
-            return;
+    uint32_t start = 0;
+    auto prepare = [&]() -> bool {
+        if (u >= n_segs) return false;
+        st = segs[u];
+        if (mode == 0) {
+            start = lo;
+            st.entry = t == 0 ? 0 : SEG_NONE;
+        } else if (mode == 1) {
+            const uint32_t own = outs[u].v[rd];
+            const uint32_t e = t == 0 ? 0 : outs[u - 1].v[rd];
+            outs[u].v[wr] = own;  // unless decoded again below
+            if (e == SEG_NONE) return false;  // the predecessor has nothing to say yet
+            st.entry = e;
+            if (e >= hi || e >= end_bits) {  // no MCU begins in this segment (or, in a damaged stream, the predecessor ran past the end of the scan: nothing is decoded from there): pass the position on
+                st.from = e;
+                outs[u].v[wr] = e;
+                segs[u] = st;
+                return false;
+            }
+            if (e == st.from || (st.from == lo && e >= lo && ((bm[(e - lo) >> 5] >> ((e - lo) & 31)) & 1u))) {  // the last decode went through e: its `out` stands
+                segs[u] = st;
+                return false;
+            }
+            start = e;
+        } else {
+            if (st.entry == SEG_NONE || st.entry >= hi || st.entry >= end_bits) {
+                st.count = 0;
+                st.dc[0] = st.dc[1] = st.dc[2] = 0;
+                st.out_check = st.entry;
+                segs[u] = st;
+                return false;
+            }
+            // Most lanes decoded from exactly this entry in a validation round (a decode that starts mid-stream is rarely in step by the first
+            // MCU of its segment, so round 1 sent it back to the predecessor's exit): the counts of that decode stand, nothing is decoded again.
+            if (st.from == st.entry) return false;
+            start = st.entry;
         }
-        if (e == st.from || (st.from == lo && e >= lo && ((bm[(e - lo) >> 5] >> ((e - lo) & 31)) & 1u))) {  // the last decode went through e: its `out` stands
-            segs[u] = st;
-            return;
-        }
-        start = e;
-    } else {
-        st.count = 0;
-        st.dc[0] = st.dc[1] = st.dc[2] = 0;
-        st.out_check = st.entry;
-        if (st.entry == SEG_NONE || st.entry >= hi || st.entry >= end_bits) {
-            segs[u] = st;
-            return;
-        }
-        start = st.entry;
+        return true;
+    };
+    const bool active = prepare();
+    if (!__syncthreads_or(active)) return;
+    if (LDS_TABLES > 0) {  // four waves share one copy of the chunk's tables
+        const uint4 *src = reinterpret_cast<const uint4 *>(g_luts);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_luts);
+        const uint32_t words = n_luts * (uint32_t)(sizeof(rphj::DeviceLut) / 16);
+        for (uint32_t w = threadIdx.x; w < words; w += SYNC_BLOCK) dst[w] = src[w];
+        __syncthreads();
     }
+    if (!active) return;
     // ---- decode from bit `start` of the scan, MCU after MCU, until one begins at or behind `hi`
     const uint32_t ns = S->ns;
     uint32_t H0, H1, H2, V0, V1, V2;
@@ -1036,14 +1062,12 @@ __global__ void __launch_bounds__(64) jpeg_sync_kernel(const uint8_t *__restrict
             }
         }
     }
+    // every decode leaves its counts beside the position it started from: (from, count, dc, out_check) describe one and the same decode
     st.from = start;
-    if (mode == 2) {
-        st.count = out == SEG_NONE ? 0 : count;
-        st.dc[0] = dc0, st.dc[1] = dc1, st.dc[2] = dc2;
-        st.out_check = out;
-    } else {
-        outs[u].v[mode == 0 ? 0 : wr] = out;
-    }
+    st.count = out == SEG_NONE ? 0 : count;
+    st.dc[0] = dc0, st.dc[1] = dc1, st.dc[2] = dc2;
+    st.out_check = out;
+    if (mode != 2) outs[u].v[mode == 0 ? 0 : wr] = out;
     segs[u] = st;
 }
 
@@ -1148,7 +1172,7 @@ int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HIm
 }
 
 int rph_jpeg_launch_segments(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const SegFile *d_files, uint32_t n_files, SegState *d_segs,
-                             uint32_t n_segs, uint32_t seg_bytes, uint32_t *d_bitmap, int rounds, const rphj::DeviceLut *d_luts, HItem *d_items)
+                             uint32_t n_segs, uint32_t seg_bytes, uint32_t *d_bitmap, int rounds, const rphj::DeviceLut *d_luts, uint32_t n_luts, HItem *d_items)
 {
     if (n_files == 0 || n_segs == 0) return RPH_OK;
     // d_bitmap: n_segs * seg_bytes of marks, then n_segs double-buffered `out` positions, then the segment -> file map
@@ -1158,11 +1182,18 @@ int rph_jpeg_launch_segments(hipStream_t stream, const uint8_t *d_streams, const
     RPH_HIP_CHECK(hipMemsetAsync(d_bitmap, 0, (size_t)n_segs * seg_bytes, stream));
     RPH_HIP_CHECK(hipMemsetAsync(d_outs, 0xFF, (size_t)n_segs * sizeof(SegOut2), stream));
     RPH_HIP_CHECK(hipMemsetAsync(d_segs, 0xFF, (size_t)n_segs * sizeof(SegState), stream));
-    const dim3 grid((n_segs + 63) / 64);
-    hipLaunchKernelGGL(jpeg_sync_kernel, grid, dim3(64), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_bitmap, 0, 0, d_luts);
-    for (int r = 1; r <= rounds; r++)
-        hipLaunchKernelGGL(jpeg_sync_kernel, grid, dim3(64), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_bitmap, 1, r, d_luts);
-    hipLaunchKernelGGL(jpeg_sync_kernel, grid, dim3(64), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_bitmap, 2, 0, d_luts);
+    const dim3 grid((n_segs + SYNC_BLOCK - 1) / SYNC_BLOCK);
+    auto sync = [&](int mode, int round) {
+        if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
+            hipLaunchKernelGGL(jpeg_sync_kernel<HUFF_LDS_TABLES>, grid, dim3(SYNC_BLOCK), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_bitmap,
+                               mode, round, d_luts, n_luts);
+        else
+            hipLaunchKernelGGL(jpeg_sync_kernel<0>, grid, dim3(SYNC_BLOCK), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_bitmap, mode, round,
+                               d_luts, n_luts);
+    };
+    sync(0, 0);
+    for (int r = 1; r <= rounds; r++) sync(1, r);
+    sync(2, 0);
     hipLaunchKernelGGL(jpeg_seg_items_kernel, dim3((n_files + 63) / 64), dim3(64), 0, stream, d_files, n_files, d_segs, d_outs, rounds & 1, d_items);
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;

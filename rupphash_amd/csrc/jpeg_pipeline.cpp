@@ -880,7 +880,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 uint32_t *d_bitmap = reinterpret_cast<uint32_t *>(S.d_segwork + align_up((size_t)n_segs * sizeof(SegState), 16));
                 RPH_TRY(rph_jpeg_launch_segments(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const SegFile *>(S.meta.d + off_segf),
                                                  (uint32_t)seg_files.size(), d_segs, n_segs, ctx->jpeg_seg_bytes, d_bitmap, 8,
-                                                 reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), reinterpret_cast<HItem *>(S.meta.d + off_items)));
+                                                 reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), reinterpret_cast<HItem *>(S.meta.d + off_items)));
             }
             lap(t_seg);
             RPH_HIP_CHECK(hipMemsetAsync(d_coef, 0, blocks * 128, s));
