@@ -595,7 +595,7 @@ def jpeg_leg(eng, np, args, oracle):
             nv = 64  # distinct crops: 16 horizontal x 4 vertical offsets
             with ThreadPoolExecutor(max_workers=cores) as pool:
                 variants = list(pool.map(photo, [(k % 16, k // 16, kw) for k in range(nv)]))
-            m_ph = 20000 if label == "photos_baseline" else 8000
+            m_ph = 20000
             ph = eng.jpeg_file_list([variants[k % nv] for k in range(m_ph)])
             eng.jpeg_pdq_hash_batch(ph, threads=cores)
             t0 = time.perf_counter()

@@ -165,6 +165,11 @@ struct JpegPipe {
 constexpr size_t CHUNK_COEF_BYTES = (size_t)192 << 20;   // host entropy, per slot: ~250 images of 512x512 4:2:0
 constexpr size_t SUB_COEF_BYTES = (size_t)4 << 30;        // device entropy: reconstruction sub-batch (~5400 such images)
 constexpr size_t MAX_IMAGE_COEF_BYTES = (size_t)3 << 30;  // one image beyond this is refused (RPH_ERR_UNSUPPORTED)
+// A frame header may announce any geometry: a file of a few hundred bytes that declares 20000 x 20000 would have gigabytes of pinned
+// memory zeroed on its behalf.  Every coded block takes at least one bit of the file (sequential: a DC category code and an end-of-block
+// code, two bits; a progressive file's first DC scan: one), so a header that announces more blocks than eight per file byte cannot be honest:
+// refused before anything is allocated.
+static inline bool frame_is_plausible(const rphj::Frame &f, size_t file_len) { return (size_t)f.total_blocks <= 8 * file_len + 64; }
 constexpr uint32_t CHUNK_MAX_IMAGES = 4096;               // host entropy
 constexpr size_t SUB_MAX_IMAGES = 16384;                  // images per reconstruction sub-batch (grid.y of the kernels: 3 planes each)
 constexpr uint32_t DEVICE_ENTROPY_MIN_FILES = 2048;       // automatic mode: below this many lanes (files, or restart intervals) the host decodes (latency)
@@ -945,7 +950,7 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
             j.len = len[i];
             j.pre = nullptr;
             j.status = (j.data && j.len) ? rphj::parse_frame(j.data, j.len, j.frame) : RPH_ERR_INVALID_ARG;
-            if (j.status == RPH_OK && j.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) j.status = RPH_ERR_UNSUPPORTED;
+            if (j.status == RPH_OK && (j.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES || !frame_is_plausible(j.frame, j.len))) j.status = RPH_ERR_UNSUPPORTED;
         });
     RPH_JPEG_STAMP("frames parsed");
     // Which files walk their Huffman streams on the device?  In automatic mode, those for which it is estimated to pay:
@@ -1170,7 +1175,7 @@ int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int fla
         OneRequest me;
         me.data = data, me.len = len, me.flavour = flavour, me.want_coeffs = coeffs_out != nullptr, me.done = false, me.valid = 0, me.quality = 0.f, me.coef = nullptr;
         me.status = rphj::parse_frame(data, len, me.frame);
-        if (me.status == RPH_OK && me.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES) me.status = RPH_ERR_UNSUPPORTED;
+        if (me.status == RPH_OK && (me.frame.total_blocks * 128 > MAX_IMAGE_COEF_BYTES || !frame_is_plausible(me.frame, len))) me.status = RPH_ERR_UNSUPPORTED;
         if (me.status == RPH_OK) {
             const size_t need = (size_t)me.frame.total_blocks * 128;
             if (tls_coef.owner != ctx || tls_coef.serial != ctx->serial) tls_coef = ThreadPinned();  // another (or an earlier) context's buffer is not ours to use

@@ -362,3 +362,18 @@ def test_scanner_load_image_fast_mirror(eng, oracle):
     assert scanner.load_image_fast("g.jpeg", gray, engine=eng).shape == (30, 40)
     with pytest.raises(ValueError):
         scanner.load_image_fast("file.png", data, engine=eng)  # other formats stay with the host's decoders
+
+
+def test_header_that_announces_more_blocks_than_the_file_can_hold_is_refused(eng):
+    """a 20000 x 20000 frame header on a file of a few hundred bytes (header-only decompression bomb): RPH_ERR_UNSUPPORTED before
+    anything is allocated, in the batch call and in the one-file call"""
+    import jpeg_util as ju
+
+    f = bytearray(ju.pillow_jpeg(ju.make_image(16, 16), quality=50))
+    sof = f.find(b"\xff\xc0")
+    assert sof > 0
+    f[sof + 5:sof + 9] = (20000).to_bytes(2, "big") + (20000).to_bytes(2, "big")  # height, width
+    out = eng.jpeg_pdq_hash_batch([bytes(f)], threads=1)
+    assert not out["valid"][0] and out["status"][0] == -5
+    with pytest.raises(Exception):
+        eng.jpeg_pdq_hash_one(bytes(f))

@@ -26,7 +26,7 @@ pdq, ham, rs = pick("pdq_fused512"), pick("hamming_mfma"), pick("read_stream")
 N_IMG, IMG, PASSES = 30000, 786432, 7
 per = lambda k, c: k[c] / (k["_dispatches"] / PASSES)  # per launch: every pass runs the same launches, each counter lives in one pass
 out = [f"rocprofv3 --pmc passes ({tag}; tools/run_pmc.sh: one counter group per run, --kernel-trace only), command per pass:",
-       "  python3 bench.py --steps 2 --warmup 1 --images 30000 --hashes 1000000 --no-e2e --no-cpu-baseline --no-reference-cases",
+       "  python3 bench.py --steps 2 --warmup 1 --images 30000 --hashes 1000000 --no-e2e --no-jpeg --hashes-strong 0 --no-cpu-baseline --no-reference-cases",
        f"Raw per-kernel sums: {tag}_pmc_raw.txt.  Per pass: 3 launches of the PDQ kernel (30000 images = 23.59 GB algorithmic read each), 3 sweeps of",
        "1 000 448 hashes at threshold 32, 4 launches of the read-stream kernel over the same 23.59 GB.  SQ_* cycle counters are in units of 4 clocks.", ""]
 # calibration of FETCH_SIZE on a known byte count
@@ -44,9 +44,9 @@ out += ["pdq_fused512_kernel<Geo<64>> (bench default)",
         f"{fetch / N_IMG / IMG:.3f} x algorithmic",
         f"    (L2 -> fabric requests, Infinity-Cache hits included: a 192-B strip row straddles 128-B lines); TCC_MISS_sum x 128 B = "
         f"{per(pdq, 'TCC_MISS_sum') * 128 / 1e9:.2f} GB agrees; TCC hit rate {pdq['TCC_HIT_sum'] / pdq['TCC_REQ_sum'] * 100:.0f} %",
-        f"  WRITE_SIZE {per(pdq, 'WRITE_SIZE'):.0f} KB per launch = {per(pdq, 'WRITE_SIZE') * 1024 / N_IMG:.0f} B/image (32-byte hashes + the scratch of ten VGPRs this build spills at",
-        "    band boundaries, a few dwords per lane and image; the 128-px strip build spills none)",
-        f"  SQ_INSTS_VALU {per(pdq, 'SQ_INSTS_VALU') / N_IMG:.0f} per image (round 1: 64 784), SQ_INSTS_LDS {per(pdq, 'SQ_INSTS_LDS') / N_IMG:.0f}, SQ_INSTS_SALU "
+        f"  WRITE_SIZE {per(pdq, 'WRITE_SIZE'):.0f} KB per launch = {per(pdq, 'WRITE_SIZE') * 1024 / N_IMG:.0f} B/image (the 32-byte hashes: no VGPR is spilled since the column",
+        "    recurrences' states wait in LDS between strips, round 3; round 2 wrote 5 152 B per image of scratch)",
+        f"  SQ_INSTS_VALU {per(pdq, 'SQ_INSTS_VALU') / N_IMG:.0f} per image (round 1: 64 784, round 2: 62 680), SQ_INSTS_LDS {per(pdq, 'SQ_INSTS_LDS') / N_IMG:.0f}, SQ_INSTS_SALU "
         f"{per(pdq, 'SQ_INSTS_SALU') / N_IMG:.0f}, SQ_INSTS_VMEM_RD {per(pdq, 'SQ_INSTS_VMEM_RD') / N_IMG:.0f}",
         f"  wave-cycles: executing VALU {pdq['SQ_ACTIVE_INST_VALU'] / pdq['SQ_WAVE_CYCLES'] * 100:.0f} % (two waves per SIMD: the SIMD's VALU is busy ~{2 * pdq['SQ_ACTIVE_INST_VALU'] / pdq['SQ_WAVE_CYCLES'] * 100:.0f} % of the time), "
         f"SQ_WAIT_INST_ANY {pdq['SQ_WAIT_INST_ANY'] / pdq['SQ_WAVE_CYCLES'] * 100:.0f} % (LDS {pdq['SQ_WAIT_INST_LDS'] / pdq['SQ_WAVE_CYCLES'] * 100:.1f} %), SQ_WAIT_ANY {pdq['SQ_WAIT_ANY'] / pdq['SQ_WAVE_CYCLES'] * 100:.0f} %",
@@ -56,7 +56,7 @@ out += ["pdq_fused512_kernel<Geo<64>> (bench default)",
 n_mfma = per(ham, "SQ_INSTS_MFMA")
 hfetch = per(ham, "FETCH_SIZE") * 1024
 out += ["hamming_mfma_kernel<FmtFp4ZO, 4> (1 000 448 hashes, threshold 32: 5.0045e11 pairs per sweep)",
-        f"  SQ_INSTS_MFMA {n_mfma:.4g} per sweep (= 2 per 1024 pairs), SQ_INSTS_VALU {per(ham, 'SQ_INSTS_VALU'):.4g} = {per(ham, 'SQ_INSTS_VALU') / n_mfma:.2f} per MFMA (round 1: 7.4)",
+        f"  SQ_INSTS_MFMA {n_mfma:.4g} per sweep (= 2 per 1024 pairs), SQ_INSTS_VALU {per(ham, 'SQ_INSTS_VALU'):.4g} = {per(ham, 'SQ_INSTS_VALU') / n_mfma:.2f} per MFMA (round 1: 7.4, round 2: 6.41)",
         f"  SQ_VALU_MFMA_BUSY_CYCLES {per(ham, 'SQ_VALU_MFMA_BUSY_CYCLES'):.4g} (= 32 x MFMAs) / (GRBM_GUI_ACTIVE {per(ham, 'GRBM_GUI_ACTIVE'):.4g} / 8 XCDs x 1024 SIMDs) = "
         f"{per(ham, 'SQ_VALU_MFMA_BUSY_CYCLES') / (per(ham, 'GRBM_GUI_ACTIVE') / 8 * 1024) * 100:.0f} % of the cycles the matrix pipe is busy",
         f"  effective clock (GRBM_GUI_ACTIVE / 8 / kernel time, profiled run): {clk(ham, 'hamming_mfma'):.2f} GHz; in-kernel s_memtime / s_memrealtime of the same loop (tools/sweep_loop.hip): 1.78 GHz",

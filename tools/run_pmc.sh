@@ -3,7 +3,7 @@
 # --kernel-trace only, one counter group per run as MI355X_MICROARCH.md prescribes).  The read-stream kernel of the same run (a known
 # byte count) calibrates FETCH_SIZE.  Raw per-kernel sums -> gpurun_out/pmc_TAG/raw.txt (tools/pmc_summary.py).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_$TAG
@@ -11,7 +11,7 @@ rm -rf $OUT && mkdir -p $OUT
 i=0
 while read -r p; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc $p -d $OUT/pass$i -o run -- python3 $R/bench.py --steps 2 --warmup 1 --images 30000 --hashes 1000000 --no-e2e --no-cpu-baseline --no-reference-cases > $OUT/pass$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc $p -d $OUT/pass$i -o run -- python3 $R/bench.py --steps 2 --warmup 1 --images 30000 --hashes 1000000 --no-e2e --no-jpeg --hashes-strong 0 --no-cpu-baseline --no-reference-cases > $OUT/pass$i.log 2>&1
 done <<'LIST'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU
 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IFETCH

@@ -6,10 +6,11 @@
 #                                                                                                    quality + 8 dihedral hashes and take longer)
 #   gpurun_out/prof_TAG/thr40/     python3 bench.py --only hamming --threshold 40 ...              (the scanner's default similarity)
 #   gpurun_out/prof_TAG/thr63/     python3 bench.py --only hamming --threshold 63 ...              (MAX_SIMILARITY_256)
+#   gpurun_out/prof_TAG/config5/   python3 bench.py --only hamming_10m ...                         (BASELINE config 5: 10 000 000 hashes, on the GPUs given)
 #   gpurun_out/prof_TAG/jpeg/      python3 bench.py --only jpeg ...                                (row N3: JPEG files -> hashes; 5 calls of 100 000 files
 #                                                                                                    with the Huffman walk on the device + 2 of 8 000 with host entropy decoding)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
@@ -20,8 +21,9 @@ run() {  # name, bench args...
   python3 $R/tools/show_bench.py $OUT/$name.json
   grep -E "pdq_fused512|hamming_mfma|read_stream|jpeg_" $OUT/$name/run_kernel_stats.csv | cut -c1-200
 }
-run default --no-e2e --no-jpeg
+run default --no-e2e --no-jpeg --hashes-strong 0
 run e2e --only e2e
 run thr40 --only hamming --threshold 40
 run thr63 --only hamming --threshold 63
+run config5 --only hamming_10m
 run jpeg --only jpeg
