@@ -373,7 +373,11 @@ def test_header_that_announces_more_blocks_than_the_file_can_hold_is_refused(eng
     sof = f.find(b"\xff\xc0")
     assert sof > 0
     f[sof + 5:sof + 9] = (20000).to_bytes(2, "big") + (20000).to_bytes(2, "big")  # height, width
-    out = eng.jpeg_pdq_hash_batch([bytes(f)], threads=1)
-    assert not out["valid"][0] and out["status"][0] == -5
-    with pytest.raises(Exception):
+    good = ju.pillow_jpeg(ju.make_image(64, 48), quality=80)
+    out = eng.jpeg_pdq_hash_batch([bytes(f), good], threads=1)  # (a batch reports per file; a call of ONE file returns the file's status)
+    assert not out["valid"][0] and out["status"][0] == -5 and out["valid"][1] and out["status"][1] == 0
+    from rupphash_amd import RphError
+
+    with pytest.raises(RphError) as e:
         eng.jpeg_pdq_hash_one(bytes(f))
+    assert e.value.status == -5
