@@ -415,7 +415,8 @@ __global__ void __launch_bounds__(64, 2) pdq_stream_kernel(const uint8_t *__rest
 
 // to_luma601 (pdqhash.rs:268-284) of Rgb8 / Rgba8 pixels into a Luma8 plane with 16-byte aligned rows: four pixels per thread, whole dwords in
 // and out.  The streaming kernel takes its A operand -- 16 luma bytes per lane -- straight from memory, so colour inputs pass through this
-// plane (read 3 or 4 bytes, write 1, read 1 per pixel).
+// plane (read 3 or 4 bytes, write 1, read 1 per pixel); so do Luma8 inputs whose rows do not start on dword boundaries (CH = 1: a copy).
+// Source rows of any alignment: aligned dwords + v_alignbyte.
 template <int CH>
 __global__ void __launch_bounds__(256) st_luma_kernel(const uint8_t *__restrict__ px, uint32_t w, uint32_t h, size_t row_stride, size_t image_stride,
                                                       uint8_t *__restrict__ out, uint32_t out_pitch, size_t out_stride)
@@ -427,19 +428,29 @@ __global__ void __launch_bounds__(256) st_luma_kernel(const uint8_t *__restrict_
     const uint8_t *p = px + (size_t)blockIdx.y * image_stride + (size_t)y * row_stride + (size_t)q * 4 * CH;
     uint32_t d[CH];
     if (q * 4 + 4 <= w) {
+        const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
+        const uint32_t *p4 = reinterpret_cast<const uint32_t *>(p - sh);
+        uint32_t raw[CH + 1];
 #pragma unroll
-        for (int i = 0; i < CH; i++) d[i] = reinterpret_cast<const uint32_t *>(p)[i];
+        for (int i = 0; i < CH; i++) raw[i] = p4[i];
+        raw[CH] = sh ? p4[CH] : 0u;  // (with sh != 0 that dword holds bytes of this quad: it is the image's own; with sh == 0 it is not touched)
+#pragma unroll
+        for (int i = 0; i < CH; i++) d[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], sh);
     } else {  // the row's last, partial quad: byte by byte, nothing is read behind the row
 #pragma unroll
         for (int i = 0; i < CH; i++) d[i] = 0;
         for (uint32_t b = 0; b < (w - q * 4) * CH; b++) d[b >> 2] |= (uint32_t)p[b] << (8 * (b & 3));
     }
     uint32_t o = 0;
+    if (CH == 1) {
+        o = d[0];
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int B = i * CH;
-        const uint32_t r = (d[B >> 2] >> (8 * (B & 3))) & 0xFFu, g = (d[(B + 1) >> 2] >> (8 * ((B + 1) & 3))) & 0xFFu, b = (d[(B + 2) >> 2] >> (8 * ((B + 2) & 3))) & 0xFFu;
-        o |= ((299u * r + 587u * g + 114u * b + 500u) / 1000u) << (8 * i);
+        for (int i = 0; i < 4; i++) {
+            const int B = i * CH;
+            const uint32_t r = (d[B >> 2] >> (8 * (B & 3))) & 0xFFu, g = (d[(B + 1) >> 2] >> (8 * ((B + 1) & 3))) & 0xFFu, b = (d[(B + 2) >> 2] >> (8 * ((B + 2) & 3))) & 0xFFu;
+            o |= ((299u * r + 587u * g + 114u * b + 500u) / 1000u) << (8 * i);
+        }
     }
     reinterpret_cast<uint32_t *>(out + (size_t)blockIdx.y * out_stride + (size_t)y * out_pitch)[q] = o;
 }
@@ -452,11 +463,12 @@ bool rph_pdq_stream_supported(const uint8_t *d_px, uint32_t w, uint32_t h, uint3
            (size_t)h * row_stride < ((size_t)1 << 30);
 }
 
-// Rgb8 / Rgba8 images of the same geometries: a Luma8 plane in the context's scratch, then the streaming kernel.  Called with ctx->mu held.
+// Rgb8 / Rgba8 images of the same geometries, and Luma8 images whose rows do not lie on dword boundaries: a Luma8 plane with aligned rows
+// in the context's scratch, then the streaming kernel.  Called with ctx->mu held.
 bool rph_pdq_stream_color_supported(const uint8_t *d_px, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride, size_t image_stride)
 {
-    return (channels == 3 || channels == 4) && w >= 128 && w <= 512 && h >= 128 && h <= 512 && (row_stride % 4) == 0 && (image_stride % 4) == 0 &&
-           ((uintptr_t)d_px % 4) == 0;
+    (void)d_px, (void)row_stride, (void)image_stride;  // any alignment
+    return (channels == 1 || channels == 3 || channels == 4) && w >= 128 && w <= 512 && h >= 128 && h <= 512;
 }
 
 int rph_launch_pdq_stream_color(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, uint32_t w, uint32_t h, uint32_t channels, size_t row_stride, size_t image_stride,
@@ -484,7 +496,9 @@ int rph_launch_pdq_stream_color(rph_ctx *ctx, const uint8_t *d_px, uint32_t n, u
         const uint32_t m = (n - first) < chunk ? (n - first) : chunk;
         const dim3 grid((quads * h + 255) / 256, m);
         const uint8_t *src = d_px + (size_t)first * image_stride;
-        if (channels == 3)
+        if (channels == 1)
+            hipLaunchKernelGGL(st_luma_kernel<1>, grid, dim3(256), 0, stream, src, w, h, row_stride, image_stride, luma, pitch, plane);
+        else if (channels == 3)
             hipLaunchKernelGGL(st_luma_kernel<3>, grid, dim3(256), 0, stream, src, w, h, row_stride, image_stride, luma, pitch, plane);
         else
             hipLaunchKernelGGL(st_luma_kernel<4>, grid, dim3(256), 0, stream, src, w, h, row_stride, image_stride, luma, pitch, plane);

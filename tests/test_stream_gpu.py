@@ -131,3 +131,38 @@ def test_stream_kernel_colour_inputs(eng, oracle, w, h, ch):
     ref = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
     eng.set_pdq_kernel(4)
     assert np.array_equal(bits(out["coeffs"]), bits(ref["coeffs"])) and np.array_equal(out["hash"], ref["hash"])
+
+
+@pytest.mark.parametrize("w,h,ch", [(129, 131, 1), (341, 512, 1), (511, 509, 1), (333, 200, 3), (203, 307, 3), (255, 257, 4)])
+def test_stream_kernel_rows_of_any_alignment(eng, oracle, w, h, ch):
+    """packed rows whose length is not a multiple of four (Luma8 of odd width; Rgb8 rows of 3 w bytes): realigned / converted into a plane
+    with 16-byte rows by aligned dwords + v_alignbyte, then the streaming kernel; also from a base address that is not dword aligned"""
+    from rupphash_amd._lib import check as rc_check
+
+    rng = np.random.default_rng(w + 7 * h + ch)
+    n = 5
+    shape = (n, h, w) if ch == 1 else (n, h, w, ch)
+    imgs = rng.integers(0, 256, shape, dtype=np.uint8)
+    eng.set_pdq_kernel(6)
+    out = eng.pdq_hash_batch(imgs, want_quality=True, want_coeffs=True, want_dihedral=True)
+    # the same pixels one byte into a larger buffer: every row misaligned differently
+    per = h * w * ch
+    buf = np.zeros(n * per + 8, np.uint8)
+    buf[1:1 + n * per] = imgs.reshape(-1)
+    d_px, d_h = eng.dev_alloc(buf.nbytes), eng.dev_alloc(n * 32)
+    try:
+        eng.dev_upload(d_px, buf)
+        eng.pdq_hash_batch_dev(d_px + 1, n, w, h, ch, d_h)
+        eng.synchronize()
+        shifted = np.zeros((n, 32), np.uint8)
+        eng.dev_download(shifted, d_h)
+    finally:
+        eng.dev_free(d_px)
+        eng.dev_free(d_h)
+        eng.set_pdq_kernel(4)
+    for k in range(n):
+        rc, coeffs, q = oracle.pdq_features(imgs[k])
+        assert rc == 0 and out["valid"][k] == 1
+        assert np.array_equal(bits(out["coeffs"][k]), bits(coeffs)), k
+        assert bits(out["quality"][k:k + 1])[0] == bits(np.float32(q))[()]
+        assert np.array_equal(out["hash"][k], oracle.to_hash(coeffs)) and np.array_equal(shifted[k], oracle.to_hash(coeffs))

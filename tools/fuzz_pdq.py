@@ -54,8 +54,8 @@ while time.time() - t0 < budget:
         assert np.array_equal(outs[0]["coeffs"].view(np.uint32), other["coeffs"].view(np.uint32))
         assert np.array_equal(outs[0]["quality"].view(np.uint32), other["quality"].view(np.uint32))
     total += len(batch)
-    # the streaming kernel against the multi-pass kernels: crops at a random geometry, gray (rows padded to whole dwords when the width is a
-    # multiple of four: packed rows of other widths take the multi-pass kernels in every mode) and colour
+    # the streaming kernel against the multi-pass kernels: crops at a random geometry, gray (packed rows of a width that is a multiple of
+    # four are read in place; every other width is realigned into a plane with 16-byte rows first) and colour (always through the plane)
     w, h = int(rng.integers(128, 513)), int(rng.integers(128, 513))
     if rng.random() < 0.6:
         w &= ~3
