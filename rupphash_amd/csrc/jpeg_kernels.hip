@@ -121,10 +121,48 @@ __device__ __forceinline__ void idct_stb(int32_t &s0, int32_t &s1, int32_t &s2, 
     s4 = SUB(x3, t0) >> SHIFT;
 }
 
+// x's low popcount(m) bits to the set positions of m, the lowest to the lowest (Hacker's Delight 7-5, `expand`)
+__device__ __forceinline__ unsigned long long deposit64(unsigned long long x, unsigned long long m)
+{
+    const unsigned long long m0 = m;
+    unsigned long long mk = ~m << 1, mv[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        unsigned long long mp = mk ^ (mk << 1);
+        mp ^= mp << 2;
+        mp ^= mp << 4;
+        mp ^= mp << 8;
+        mp ^= mp << 16;
+        mp ^= mp << 32;
+        mv[i] = mp & m;
+        m = (m ^ mv[i]) | (mv[i] >> (1 << i));
+        mk &= ~mp;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        const unsigned long long t = x << (1 << i);
+        x = (x & ~mv[i]) | (t & mv[i]);
+    }
+    return x & m0;
+}
+
+// zigzag position of the coefficient at natural index n
+__device__ constexpr int unzigzag(int n)
+{
+    constexpr int zz[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    for (int p = 0; p < 64; p++)
+        if (zz[p] == n) return p;
+    return 0;
+}
+
 // grid: x = groups of 256 blocks of a plane, y = plane.  Lane = block: neighbouring lanes write neighbouring 8-byte row segments.
+// Planes of progressive files walked on the device carry the records of their AC refinement scans (jpeg_device.h, PCorr): the
+// corrections are added here, scan by scan in file order, by T.81 G.1.2.3's rule as libjpeg applies it -- a coefficient with history whose
+// correction bit is set moves away from zero by 1 << Al, unless that bit of it is set already (a damaged stream).
 template <int FL>
 __global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t *__restrict__ coef, const uint16_t *__restrict__ qts, const JPlane *__restrict__ planes,
-                                                        uint8_t *__restrict__ out)
+                                                        uint8_t *__restrict__ out, const PRef *__restrict__ refs, const PCorr *__restrict__ corr)
 {
     const JPlane pl = planes[blockIdx.y];
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
@@ -139,10 +177,29 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t *__restric
         const uint32_t u[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            c[8 * y + 2 * i] = MUL((int32_t)(int16_t)(u[i] & 0xFFFFu), (int32_t)qt[8 * y + 2 * i]);          // T.81 A.3.4
-            c[8 * y + 2 * i + 1] = MUL((int32_t)(int16_t)(u[i] >> 16), (int32_t)qt[8 * y + 2 * i + 1]);
+            c[8 * y + 2 * i] = (int32_t)(int16_t)(u[i] & 0xFFFFu);
+            c[8 * y + 2 * i + 1] = (int32_t)(int16_t)(u[i] >> 16);
         }
     }
+    if (pl.ref_count && bx < pl.real_bw && by < pl.real_bh) {
+        for (uint32_t q = 0; q < pl.ref_count; q++) {
+            const PRef rf = refs[pl.ref_first + q];
+            const PCorr rc = corr[(size_t)rf.corr_first + by * pl.real_bw + bx];
+            if (rc.bits == 0) continue;
+            const unsigned long long dep = deposit64(rc.bits, rc.history);
+            const uint32_t lo = (uint32_t)dep, hi = (uint32_t)(dep >> 32);
+            const int32_t p1 = 1 << rf.al;
+#pragma unroll
+            for (int n = 1; n < 64; n++) {
+                const int p = unzigzag(n);
+                const uint32_t bit = ((p < 32 ? lo : hi) >> (p & 31)) & 1u;
+                const int32_t v = c[n];
+                c[n] = (bit && (v & p1) == 0) ? (v >= 0 ? v + p1 : v - p1) : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 64; n++) c[n] = MUL(c[n], (int32_t)qt[n]);  // T.81 A.3.4
 #pragma unroll
     for (int x = 0; x < 8; x++) {
         if (FL == RPH_JPEG_LIBJPEG)
@@ -514,18 +571,22 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Progressive files (T.81 G.1.2), one per lane: the scans of a file run one after the other in the lane, each over the file's whole
-// block grid -- first DC (difference coding, value << Al), DC refinement (one bit per block), first AC of a band (runs, end-of-band
-// runs over blocks), AC refinement (a correction bit for every coefficient that is already nonzero, new +-1 values in between).
+// Progressive files (T.81 G.1.2), one SCAN per lane, each over its component's whole block grid -- first DC (difference coding,
+// value << Al), DC refinement (one bit per block), first AC of a band (runs, end-of-band runs over blocks), AC refinement (a correction
+// bit for every coefficient that is already nonzero, new +-1 values in between).  A scan needs the scans before it that touch the same
+// coefficients of the same component, and no others: the host sorts the scans of all files by their depth in that order and every depth
+// is one launch (the usual ten-scan script has three: five first scans side by side, four refinements, the last luma refinement).
 // Nothing here ever waits for a coefficient to come back from memory.  First scans only write.  Refinement needs to know WHICH
-// coefficients of a block are nonzero and their signs, not their values: two 64-bit masks per block (zigzag position = bit) are kept
-// beside the coefficients -- first AC scans OR their placements in with fire-and-forget atomics, a refinement scan reads the 16 bytes
-// of the block it is about to enter one block ahead -- and a correction is a fire-and-forget atomic add of +-(1 << Al) to the dword the
-// coefficient lives in (the half-word can neither carry nor borrow: its bit Al is clear and its sign is the direction), DC refinement
-// an atomic OR.  A step of the refinement loop is one symbol with the correction bits that precede its coefficient, stepped over with
-// bit arithmetic on the masks.  (A corrupt stream may set bit Al twice where libjpeg would test it first: its result is unspecified
-// either way, and every access stays inside the file's own blocks.)
+// coefficients of a block are nonzero, not their values: one 64-bit mask per block (zigzag position = bit) is kept beside the
+// coefficients -- first AC scans and the placements of refinement scans OR into it with fire-and-forget atomics, a refinement scan
+// reads the words of the next sixteen blocks while it walks the current sixteen out of LDS.  The corrections of an AC refinement scan
+// are collected, not applied: per block the history the scan saw and the correction bits, which jpeg_prog_apply_kernel adds to the
+// coefficients afterwards with a lane per coefficient.  DC refinement is an atomic OR.  Every access stays inside the file's own blocks
+// and records whatever a damaged stream says.
 // ---------------------------------------------------------------------------------------------------------------------------
+struct LongCodes {  // of one Huffman table: exclusive upper bounds of the codes of 9..16 bits in a 16-bit window; symbol index = (window >> (16 - length)) + delta[length],
+    int32_t maxc[8], dlt[8];  // dlt[0] = delta[9], dlt[j] = delta[9 + j] - delta[8 + j]: the bounds grow with the length, so the reached ones add up to delta[length]
+};
 struct BitR {
     const uint8_t *sbase;
     uint32_t limit, q0n, woff;
@@ -568,11 +629,18 @@ struct BitR {
         nb -= (int)n;
         return v;
     }
+    __device__ __forceinline__ uint32_t take32(uint32_t n)  // n in 0..32 bits
+    {
+        const uint32_t v = (uint32_t)((acc >> 1) >> (63 - n));
+        acc <<= n;
+        nb -= (int)n;
+        return v;
+    }
     // one Huffman symbol; 0x100 = not a code of this table.  The lane's own copy of its scan's table in LDS: look8 = 8-bit lookup
-    // ([prefix * 64 + lane]; 0 = longer code), and for the longer codes the canonical arrays (maxc / dlt: [length * 64 + lane], syms:
-    // [index * 64 + lane]).  With the long codes left in global memory nearly every step of a wave paid for one: each lane meets one
-    // only every few dozen symbols, but one lane in 64 is enough.
-    __device__ __forceinline__ uint32_t symbol8(const uint16_t *look8, const int32_t *maxc, const int32_t *dlt, const uint8_t *syms, uint32_t lane)
+    // ([prefix * 64 + lane]; 0 = longer code) and the symbols (syms: [index * 64 + lane]); for the longer codes the canonical arrays in
+    // registers (the bounds grow with the length, so the length is 9 + the number of bounds the window has reached).  With the long codes
+    // left in memory nearly every step of a wave paid for one: each lane meets one only every few dozen symbols, but one lane in 64 is enough.
+    __device__ __forceinline__ uint32_t symbol8(const uint16_t *look8, const LongCodes &lc, const uint8_t *syms, uint32_t lane)
     {
         const uint32_t e = look8[(uint32_t)(acc >> 56) * 64 + lane];
         uint32_t len, sym;
@@ -581,11 +649,17 @@ struct BitR {
             sym = e & 255;
         } else {
             const int32_t win = (int32_t)(acc >> 48);
-            uint32_t l = 9;
-            while (l <= 16 && win >= maxc[l * 64 + lane]) l++;
-            if (l > 16) return 0x100;
-            len = l;
-            sym = syms[((uint32_t)((win >> (16 - l)) + dlt[l * 64 + lane]) & 255) * 64 + lane];
+            uint32_t over = 0;
+            int32_t d = lc.dlt[0];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {  // (dlt[j] for j >= 1: the step from the length before)
+                const bool reached = win >= lc.maxc[j];
+                over += reached ? 1u : 0u;
+                if (j < 7) d += reached ? lc.dlt[j + 1] : 0;
+            }
+            if (over == 8) return 0x100;
+            len = 9 + over;
+            sym = syms[((uint32_t)((win >> (16 - len)) + d) & 255) * 64 + lane];
         }
         acc <<= len;
         nb -= (int)len;
@@ -612,18 +686,21 @@ struct BitR {
     }
 };
 
+constexpr int PROG_GROUP = 16;  // blocks of history an AC refinement lane holds in LDS at a time
+
 template <int LDS_TABLES>
 __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const PScan *__restrict__ pscans,
-                                                       const uint32_t *__restrict__ order, uint32_t n, const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts,
-                                                       int16_t *__restrict__ coef, unsigned long long *__restrict__ masks, uint8_t *__restrict__ status)
+                                                       const uint32_t *__restrict__ items, uint32_t n, const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts,
+                                                       int16_t *__restrict__ coef, unsigned long long *__restrict__ masks, PCorr *__restrict__ corr,
+                                                       uint8_t *__restrict__ status)
 {
     __shared__ uint8_t zz[80];
     __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
-    // the AC table of the lane's current scan as an 8-bit lookup of its own: progressive files carry tables optimised per scan, so a chunk has
+    // the AC table of the lane's scan as an 8-bit lookup of its own: progressive files carry tables optimised per scan, so a chunk has
     // thousands of distinct ones and they stay in global memory -- a probe there is ~1 us on the critical path of every symbol
     __shared__ uint16_t s_look8[256 * 64];
-    __shared__ int32_t s_maxc[17 * 64], s_dlt[17 * 64];
     __shared__ uint8_t s_syms[256 * 64];
+    __shared__ unsigned long long s_ring[PROG_GROUP * 64];
     for (int t = threadIdx.x; t < 80; t += 64) zz[t] = c_zigzag[t];
     if (LDS_TABLES > 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(g_luts);
@@ -635,248 +712,277 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
     __syncthreads();
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
     if (slot >= n) return;
-    const uint32_t ii = order[slot];
+    const PScan P = pscans[items[slot]];
+    const uint32_t ii = P.image;
     const HImage *im = imgs + ii;
     const uint64_t img_fb = im->first_block;
-    unsigned long long *const my_masks = masks + 2 * (size_t)im->mask_first;  // {nonzero, negative} per block of this image
+    unsigned long long *const my_masks = masks + (size_t)im->mask_first;  // nonzero positions per block of this image
     uint32_t bad = 0;
-    for (uint32_t sci = 0; sci < im->pscan_count && !bad; sci++) {
-        const PScan P = pscans[im->pscan_first + sci];
 #ifdef RPH_PROG_TIMING
-        const uint64_t t_scan = wall_clock64();
+    const uint64_t t_scan = wall_clock64();
 #endif
-        BitR b;
-        b.init(streams + im->stream_base + P.off, P.len);
-        const uint32_t al = P.al;
-        if (P.ss == 0) {
-            // ---- DC scan: MCU order (one component: its own block grid, T.81 A.2.2)
-            const uint32_t ns = P.ns;
-            const HComp *c0 = &im->comp[P.ci[0]], *c1 = &im->comp[P.ci[ns > 1 ? 1 : 0]], *c2 = &im->comp[P.ci[ns > 2 ? 2 : 0]];
-            const uint32_t H0 = ns == 1 ? 1 : c0->H, V0 = ns == 1 ? 1 : c0->V, BW0 = c0->blocks_w, FB0 = c0->first_block;
-            const uint32_t H1 = c1->H, V1 = c1->V, BW1 = c1->blocks_w, FB1 = c1->first_block;
-            const uint32_t H2 = c2->H, V2 = c2->V, BW2 = c2->blocks_w, FB2 = c2->first_block;
-            const rphj::DeviceLut *D0 = luts + P.dc[0], *D1 = luts + P.dc[ns > 1 ? 1 : 0], *D2 = luts + P.dc[ns > 2 ? 2 : 0];
-            const uint32_t MX = ns == 1 ? c0->real_bw : im->mcus_x, MY = ns == 1 ? c0->real_bh : im->mcus_y;
-            uint32_t i = 0, h = 0, v = 0, mx = 0, my = 0;
-            int p0 = 0, p1 = 0, p2 = 0;
-            bool done = MX == 0 || MY == 0;
-            while (!done) {
-                b.fill();
-                const uint32_t Hc = sel3(i, H0, H1, H2), Vc = sel3(i, V0, V1, V2), BWc = sel3(i, BW0, BW1, BW2), FBc = sel3(i, FB0, FB1, FB2);
-                const uint64_t base = (img_fb + FBc + (uint64_t)(my * Vc + v) * BWc + (mx * Hc + h)) * 64;
-                if (P.ah == 0) {
-                    const uint32_t s = b.symbol(sel3(i, D0, D1, D2));
-                    if (s > 15) {
-                        bad = 1;
-                        break;
-                    }
-                    int val = 0;
-                    if (s) {
-                        const uint32_t raw = b.take(s);
-                        val = raw < (1u << (s - 1)) ? (int)raw - (int)((1u << s) - 1) : (int)raw;
-                    }
-                    const int pv = sel3(i, p0, p1, p2) + val;
-                    p0 = i == 0 ? pv : p0;
-                    p1 = i == 1 ? pv : p1;
-                    p2 = i == 2 ? pv : p2;
-                    coef[base] = (int16_t)(pv * (1 << al));
-                } else if (b.take(1)) {
-                    atomicOr(reinterpret_cast<unsigned int *>(coef + base), 1u << al);  // coefficient 0 is the low half of the block's first dword
-                }
-                if (++h == Hc) {
-                    h = 0;
-                    if (++v == Vc) {
-                        v = 0;
-                        if (++i == ns) {
-                            i = 0;
-                            if (++mx == MX) {
-                                mx = 0;
-                                if (++my == MY) done = true;
-                            }
-                        }
-                    }
-                }
-            }
-        } else {
-            // ---- AC scan: one component, its own block grid in raster order
-            const HComp *c = &im->comp[P.ci[0]];
-            const uint32_t MX = c->real_bw, MY = c->real_bh, BW = c->blocks_w, total = MX * MY;
-            const uint64_t comp_base = img_fb + c->first_block;
-            const rphj::DeviceLut *A = luts + P.ac;
-            const uint32_t ss = P.ss, se = P.se;
-            for (uint32_t i0 = 0; i0 < 256; i0 += 16) {
-                uint16_t e[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++) e[j] = A->look[(i0 + j) << 2];
-#pragma unroll
-                for (int j = 0; j < 16; j++) s_look8[(i0 + j) * 64 + lane] = (e[j] >> 8) <= 8 ? e[j] : (uint16_t)0;
-            }
-            for (uint32_t l = 9; l <= 16; l++) {
-                s_maxc[l * 64 + lane] = A->maxcode[l];
-                s_dlt[l * 64 + lane] = A->delta[l];
-            }
-            for (uint32_t i0 = 0; i0 < 256; i0 += 16) {
-                uint32_t w4[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) w4[j] = reinterpret_cast<const uint32_t *>(A->sym)[i0 / 4 + j];
-#pragma unroll
-                for (int j = 0; j < 16; j++) s_syms[(i0 + j) * 64 + lane] = (uint8_t)(w4[j >> 2] >> (8 * (j & 3)));
-            }
-            auto block_at = [&](uint32_t bl) -> uint64_t { return (comp_base + (uint64_t)(bl / MX) * BW + bl % MX) * 64; };
+    BitR b;
+    b.init(streams + im->stream_base + P.off, P.len);
+    const uint32_t al = P.al;
+    if (P.ss == 0) {
+        // ---- DC scan: MCU order (one component: its own block grid, T.81 A.2.2)
+        const uint32_t ns = P.ns;
+        const HComp *c0 = &im->comp[P.ci[0]], *c1 = &im->comp[P.ci[ns > 1 ? 1 : 0]], *c2 = &im->comp[P.ci[ns > 2 ? 2 : 0]];
+        const uint32_t H0 = ns == 1 ? 1 : c0->H, V0 = ns == 1 ? 1 : c0->V, BW0 = c0->blocks_w, FB0 = c0->first_block;
+        const uint32_t H1 = c1->H, V1 = c1->V, BW1 = c1->blocks_w, FB1 = c1->first_block;
+        const uint32_t H2 = c2->H, V2 = c2->V, BW2 = c2->blocks_w, FB2 = c2->first_block;
+        const rphj::DeviceLut *D0 = luts + P.dc[0], *D1 = luts + P.dc[ns > 1 ? 1 : 0], *D2 = luts + P.dc[ns > 2 ? 2 : 0];
+        const uint32_t MX = ns == 1 ? c0->real_bw : im->mcus_x, MY = ns == 1 ? c0->real_bh : im->mcus_y;
+        uint32_t i = 0, h = 0, v = 0, mx = 0, my = 0;
+        int p0 = 0, p1 = 0, p2 = 0;
+        bool done = MX == 0 || MY == 0;
+        while (!done) {
+            b.fill();
+            const uint32_t Hc = sel3(i, H0, H1, H2), Vc = sel3(i, V0, V1, V2), BWc = sel3(i, BW0, BW1, BW2), FBc = sel3(i, FB0, FB1, FB2);
+            const uint64_t base = (img_fb + FBc + (uint64_t)(my * Vc + v) * BWc + (mx * Hc + h)) * 64;
             if (P.ah == 0) {
-                // first pass over the band: one symbol per step
-                uint32_t bl = 0, k = ss;
-                uint64_t base = total ? block_at(0) : 0;
-                unsigned long long nz_acc = 0, sg_acc = 0;  // placements in the current block
-                const uint64_t max_it = (uint64_t)total * 65 + 8;
-                for (uint64_t it = 0; bl < total && it < max_it; it++) {
-                    b.fill();
-                    const uint32_t rs = b.symbol8(s_look8, s_maxc, s_dlt, s_syms, lane);
-                    if (rs > 255) {
+                const uint32_t s = b.symbol(sel3(i, D0, D1, D2));
+                if (s > 15) {
+                    bad = 1;
+                    break;
+                }
+                int val = 0;
+                if (s) {
+                    const uint32_t raw = b.take(s);
+                    val = raw < (1u << (s - 1)) ? (int)raw - (int)((1u << s) - 1) : (int)raw;
+                }
+                const int pv = sel3(i, p0, p1, p2) + val;
+                p0 = i == 0 ? pv : p0;
+                p1 = i == 1 ? pv : p1;
+                p2 = i == 2 ? pv : p2;
+                coef[base] = (int16_t)(pv * (1 << al));
+            } else if (b.take(1)) {
+                atomicOr(reinterpret_cast<unsigned int *>(coef + base), 1u << al);  // coefficient 0 is the low half of the block's first dword
+            }
+            if (++h == Hc) {
+                h = 0;
+                if (++v == Vc) {
+                    v = 0;
+                    if (++i == ns) {
+                        i = 0;
+                        if (++mx == MX) {
+                            mx = 0;
+                            if (++my == MY) done = true;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        // ---- AC scan: one component, its own block grid in raster order
+        const HComp *c = &im->comp[P.ci[0]];
+        const uint32_t MX = c->real_bw, MY = c->real_bh, BW = c->blocks_w, total = MX * MY;
+        const uint64_t comp_base = img_fb + c->first_block;
+        const rphj::DeviceLut *A = luts + P.ac;
+        const uint32_t ss = P.ss, se = P.se;
+        for (uint32_t i0 = 0; i0 < 256; i0 += 16) {
+            uint16_t e[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) e[j] = A->look[(i0 + j) << 2];
+#pragma unroll
+            for (int j = 0; j < 16; j++) s_look8[(i0 + j) * 64 + lane] = (e[j] >> 8) <= 8 ? e[j] : (uint16_t)0;
+        }
+        for (uint32_t i0 = 0; i0 < 256; i0 += 16) {
+            uint32_t w4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) w4[j] = reinterpret_cast<const uint32_t *>(A->sym)[i0 / 4 + j];
+#pragma unroll
+            for (int j = 0; j < 16; j++) s_syms[(i0 + j) * 64 + lane] = (uint8_t)(w4[j >> 2] >> (8 * (j & 3)));
+        }
+        LongCodes lc;  // the canonical arrays for codes of 9..16 bits stay in registers: with 64 lanes nearly every step has a lane that needs them
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            lc.maxc[j] = A->maxcode[9 + j];
+            lc.dlt[j] = j ? A->delta[9 + j] - A->delta[8 + j] : A->delta[9];
+        }
+        if (P.ah == 0) {
+            // first pass over the band: one symbol per step
+            uint32_t bl = 0, k = ss, col = 0;
+            uint64_t base = comp_base * 64, row_base = comp_base * 64;
+            unsigned long long nz_acc = 0;  // placements in the current block
+            const uint64_t max_it = (uint64_t)total * 65 + 8;
+            for (uint64_t it = 0; bl < total && it < max_it; it++) {
+                b.fill();
+                const uint32_t rs = b.symbol8(s_look8, lc, s_syms, lane);
+                if (rs > 255) {
+                    bad = 1;
+                    break;
+                }
+                const uint32_t r = rs >> 4, s = rs & 15;
+                uint32_t adv = 0;  // blocks to move on by
+                if (s == 0) {
+                    if (r == 15) {
+                        k += 16;
+                        if (k > se) adv = 1;
+                    } else {  // end of band for this block and the next (1 << r) - 1 + bits
+                        uint32_t run = (1u << r) - 1;
+                        if (r) run += b.take(r);
+                        adv = 1 + run;
+                    }
+                } else {
+                    k += r;
+                    if (k > 63) {
                         bad = 1;
                         break;
                     }
-                    const uint32_t r = rs >> 4, s = rs & 15;
-                    uint32_t adv = 0;  // blocks to move on by
-                    if (s == 0) {
-                        if (r == 15) {
-                            k += 16;
-                            if (k > se) adv = 1;
-                        } else {  // end of band for this block and the next (1 << r) - 1 + bits
-                            uint32_t run = (1u << r) - 1;
-                            if (r) run += b.take(r);
-                            adv = 1 + run;
+                    const uint32_t raw = b.take(s);
+                    const int val = raw < (1u << (s - 1)) ? (int)raw - (int)((1u << s) - 1) : (int)raw;
+                    coef[base + zz[k]] = (int16_t)(val * (1 << al));
+                    nz_acc |= 1ull << k;
+                    k++;
+                    if (k > se) adv = 1;
+                }
+                if (adv) {
+                    if (nz_acc) {
+                        atomicOr(my_masks + (size_t)(base / 64 - img_fb), nz_acc);
+                        nz_acc = 0;
+                    }
+                    bl = adv > total - bl ? total : bl + adv;
+                    k = ss;
+                    if (adv == 1) {  // (the common case without a division)
+                        base += 64;
+                        if (++col == MX) {
+                            col = 0;
+                            row_base += (uint64_t)BW * 64;
+                            base = row_base;
                         }
-                    } else {
-                        k += r;
-                        if (k > 63) {
+                    } else if (bl < total) {
+                        const uint32_t row = bl / MX;
+                        col = bl - row * MX;
+                        row_base = (comp_base + (uint64_t)row * BW) * 64;
+                        base = row_base + (uint64_t)col * 64;
+                    }
+                }
+            }
+            if (bl < total) bad = 1;
+        } else {
+            // Refinement of the band.  Per block: nzb = the band's positions with nonzero history.  A step: a symbol (unless the block
+            // lies in an end-of-band run), then the correction bits of the coefficients with history that come before the symbol's own
+            // place -- the (r + 1)-th zero-history position from k on -- or, when there is no such place, up to the band's end.  The
+            // correction bits are only COLLECTED here (they are the next popcount bits of the stream, taken at once): the block's
+            // history and its correction bits go to the scan's record array, and jpeg_prog_apply_kernel adds them to the coefficients
+            // with a lane per coefficient.  The history of the next PROG_GROUP blocks lies in LDS (fetched a group ahead), so the lanes
+            // of a wave only meet at group boundaries and a slow block of one lane is averaged over the group, not paid by all 64.
+            const int p1 = 1 << al;
+            const uint64_t band = ((se >= 63 ? 0ull : (1ull << (se + 1))) - 1ull) & ~((1ull << ss) - 1ull);
+            PCorr *const rec = corr + P.corr_first;
+            uint32_t bl = 0, eobrun = 0, k = ss, col = 0, f_col = 0, f_bl = 0, cn = 0;
+            uint64_t row_base = comp_base, f_row_base = comp_base;  // in blocks
+            unsigned long long pf[PROG_GROUP];
+            auto fetch_group = [&]() {  // the history words of the next PROG_GROUP blocks (raster order over the component's real blocks)
+#pragma unroll
+                for (int j = 0; j < PROG_GROUP; j++) {
+                    pf[j] = 0;
+                    if (f_bl < total) {
+                        pf[j] = my_masks[(size_t)(f_row_base + f_col - img_fb)];
+                        f_bl++;
+                        if (++f_col == MX) {
+                            f_col = 0;
+                            f_row_base += BW;
+                        }
+                    }
+                }
+            };
+            fetch_group();
+            unsigned long long nz_all = 0, nzb = 0, cb = 0, nz_new = 0;
+            uint64_t base = 0;
+            bool fresh = true;
+            for (uint32_t g0 = 0; g0 < total && !bad; g0 += PROG_GROUP) {
+#pragma unroll
+                for (int j = 0; j < PROG_GROUP; j++) s_ring[j * 64 + lane] = pf[j];
+                fetch_group();
+                const uint32_t gend = g0 + PROG_GROUP < total ? g0 + PROG_GROUP : total;
+                while (bl < gend) {
+                    if (fresh) {
+                        nz_all = s_ring[(bl & (PROG_GROUP - 1)) * 64 + lane];
+                        nzb = nz_all & band;
+                        k = ss;
+                        cb = 0;
+                        cn = 0;
+                        nz_new = 0;
+                        base = (row_base + col) * 64;
+                        fresh = false;
+                    }
+                    b.fill();
+                    uint32_t r = 0;
+                    int value = 0;
+                    bool place = false;  // a symbol of this block asks for a place; else only corrections are due
+                    if (eobrun == 0) {
+                        const uint32_t rs = b.symbol8(s_look8, lc, s_syms, lane);
+                        if (rs > 255) {
                             bad = 1;
                             break;
                         }
-                        const uint32_t raw = b.take(s);
-                        const int val = raw < (1u << (s - 1)) ? (int)raw - (int)((1u << s) - 1) : (int)raw;
-                        coef[base + zz[k]] = (int16_t)(val * (1 << al));
-                        nz_acc |= 1ull << k;
-                        sg_acc |= (unsigned long long)(val < 0) << k;
-                        k++;
-                        if (k > se) adv = 1;
-                    }
-                    if (adv) {
-                        if (nz_acc) {
-                            unsigned long long *m = my_masks + 2 * (size_t)(base / 64 - img_fb);
-                            atomicOr(m, nz_acc);
-                            if (sg_acc) atomicOr(m + 1, sg_acc);
-                            nz_acc = sg_acc = 0;
-                        }
-                        bl = adv > total - bl ? total : bl + adv;
-                        k = ss;
-                        if (bl < total) base = block_at(bl);
-                    }
-                }
-                if (bl < total) bad = 1;
-            } else {
-                // refinement of the band.  Per block: nzb = the band's positions with nonzero history, sgn = their signs.  A step: a symbol
-                // (unless the block lies in an end-of-band run), then the correction bits of the coefficients with history that come before
-                // the symbol's own place -- the (r + 1)-th zero-history position from k on -- or, when there is no such place, up to the band's end.
-                const unsigned int p1 = 1u << al;
-                const uint64_t band = ((se >= 63 ? 0ull : (1ull << (se + 1))) - 1ull) & ~((1ull << ss) - 1ull);
-                uint32_t bl = 0, eobrun = 0;
-                unsigned long long pf_nz = 0, pf_sg = 0;
-                auto fetch = [&](uint32_t blk) {  // (past the L1: the first scans' atomics happen in the L2)
-                    const unsigned long long *m = my_masks + 2 * (size_t)(block_at(blk) / 64 - img_fb);
-                    pf_nz = __hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    pf_sg = __hip_atomic_load(m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                };
-                if (total) fetch(0);
-                for (; bl < total && !bad; bl++) {
-                    const uint64_t base = block_at(bl);
-                    const unsigned long long nz_all = pf_nz, sgn = pf_sg;
-                    const uint64_t nzb = nz_all & band;
-                    if (bl + 1 < total) fetch(bl + 1);
-                    unsigned long long nz_new = 0, sg_new = 0;
-                    uint32_t k = ss;
-                    bool block_done = false;
-                    for (int it = 0; it < 66 && !block_done; it++) {
-                        b.fill();
-                        int r = 0, value = 0;
-                        bool place = false;  // a symbol of this block asks for a place (mode 1); else only corrections are due
-                        if (eobrun == 0) {
-                            const uint32_t rs = b.symbol8(s_look8, s_maxc, s_dlt, s_syms, lane);
-                            if (rs > 255) {
+                        r = rs >> 4;
+                        const uint32_t s = rs & 15;
+                        if (s) {
+                            if (s != 1) {
                                 bad = 1;
                                 break;
                             }
-                            r = (int)(rs >> 4);
-                            const uint32_t s = rs & 15;
-                            if (s) {
-                                if (s != 1) {
-                                    bad = 1;
-                                    break;
-                                }
-                                value = b.take(1) ? (int)p1 : -(int)p1;
-                                place = true;
-                            } else if (r != 15) {
-                                eobrun = 1u << r;
-                                if (r) eobrun += b.take((uint32_t)r);
-                            } else {
-                                place = true;  // sixteen zero-history coefficients to step over, nothing to put down
-                            }
-                        }
-                        const uint64_t from_k = ~0ull << k;  // k <= 63 here
-                        uint64_t todo = nzb & from_k;         // coefficients with history that take a correction bit now
-                        uint32_t at = 64;                     // the symbol's place
-                        if (place) {
-                            uint64_t zeros = ~nzb & band & from_k;
-                            if (__builtin_popcountll(zeros) > r) {
-                                for (int q = 0; q < r; q++) zeros &= zeros - 1;
-                                at = (uint32_t)__builtin_ctzll(zeros);
-                                todo &= (1ull << at) - 1ull;
-                            }
-                        }
-                        while (todo) {
-                            b.fill();
-                            const uint32_t pos = (uint32_t)__builtin_ctzll(todo);
-                            todo &= todo - 1;
-                            if (b.take(1)) {
-                                const uint32_t nat = zz[pos];
-                                unsigned int *d = reinterpret_cast<unsigned int *>(coef + base) + (nat >> 1);
-                                const unsigned int delta = p1 << (16 * (nat & 1));
-                                if ((sgn >> pos) & 1)
-                                    atomicSub(d, delta);
-                                else
-                                    atomicAdd(d, delta);
-                            }
-                        }
-                        if (at < 64) {
-                            if (value) {
-                                coef[base + zz[at]] = (int16_t)value;
-                                nz_new |= 1ull << at;
-                                sg_new |= (unsigned long long)(value < 0) << at;
-                            }
-                            k = at + 1;
-                            if (k > se) block_done = true;
+                            value = b.take(1) ? p1 : -p1;
+                            place = true;
+                        } else if (r != 15) {
+                            eobrun = 1u << r;
+                            if (r) eobrun += b.take(r);
                         } else {
-                            block_done = true;  // an end-of-band run, or the band ended inside the symbol's run of zeros
+                            place = true;  // sixteen zero-history coefficients to step over, nothing to put down
                         }
                     }
-                    if (!block_done) bad = 1;
-                    if (eobrun > 0) eobrun--;
-                    if (nz_new) {  // (this lane is the only writer of the block's masks during a refinement scan)
-                        unsigned long long *m = my_masks + 2 * (size_t)(base / 64 - img_fb);
-                        m[0] = nz_all | nz_new;
-                        m[1] = sgn | sg_new;
+                    const uint64_t from_k = ~0ull << k;  // k <= 63 here
+                    uint64_t todo = nzb & from_k;         // coefficients with history that take a correction bit now
+                    uint32_t at = 64;                     // the symbol's place
+                    if (place) {
+                        uint64_t zeros = ~nzb & band & from_k;
+                        if ((uint32_t)__builtin_popcountll(zeros) > r) {
+                            for (uint32_t q = 0; q < r; q++) zeros &= zeros - 1;
+                            at = (uint32_t)__builtin_ctzll(zeros);
+                            todo &= (1ull << at) - 1ull;
+                        }
+                    }
+                    uint32_t nc = (uint32_t)__builtin_popcountll(todo);
+                    while (nc) {  // (twice when more than 32 are due); the first bit read belongs to the lowest position: it goes lowest
+                        b.fill();
+                        const uint32_t t = nc < 32 ? nc : 32;
+                        cb |= (unsigned long long)(__builtin_bitreverse32(b.take32(t)) >> (32 - t)) << cn;
+                        cn += t;
+                        nc -= t;
+                    }
+                    bool block_done = true;  // an end-of-band run, or the band ended inside the symbol's run of zeros
+                    if (at < 64) {
+                        if (value) {
+                            coef[base + zz[at]] = (int16_t)value;
+                            nz_new |= 1ull << at;
+                        }
+                        k = at + 1;
+                        block_done = k > se;
+                    }
+                    if (block_done) {
+                        if (nzb) *reinterpret_cast<ulonglong2 *>(rec + bl) = make_ulonglong2(nzb, cb);  // (the records were zeroed)
+                        if (nz_new) atomicOr(my_masks + (size_t)(base / 64 - img_fb), nz_new);
+                        if (eobrun > 0) eobrun--;
+                        bl++;
+                        if (++col == MX) {
+                            col = 0;
+                            row_base += BW;
+                        }
+                        fresh = true;
                     }
                 }
-                if (bl < total) bad = 1;
             }
+            if (bl < total) bad = 1;
         }
-#ifdef RPH_PROG_TIMING
-        if (slot == 0) printf("scan %u ns=%u ss=%u se=%u ah=%u al=%u len=%u: %llu us\n", sci, P.ns, P.ss, P.se, P.ah, P.al, P.len, (unsigned long long)(wall_clock64() - t_scan) / 100);
-#endif
     }
-    if (bad) status[ii] = 1;
+#ifdef RPH_PROG_TIMING
+    if (ii == 0) printf("scan ns=%u ss=%u se=%u ah=%u al=%u len=%u: %llu us\n", P.ns, P.ss, P.se, P.ah, P.al, P.len, (unsigned long long)(wall_clock64() - t_scan) / 100);
+#endif
+    if (bad) status[ii] = 1;  // (the results were zeroed before the launch; the scans of a file are different lanes)
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Segments of a stream without restart markers (jpeg_device.h): one lane per segment.  mode 0: decode from the segment boundary as if an
@@ -1123,13 +1229,13 @@ __global__ void __launch_bounds__(64) jpeg_seg_items_kernel(const SegFile *__res
 }  // namespace
 
 int rph_jpeg_launch_idct(int flavour, uint32_t max_blocks, uint32_t n_planes, hipStream_t stream, const int16_t *d_coef, const uint16_t *d_tables, const JPlane *d_planes,
-                         uint8_t *d_samples)
+                         uint8_t *d_samples, const PRef *d_refs, const PCorr *d_corr)
 {
     const dim3 grid((max_blocks + 255) / 256, n_planes);
     if (flavour == RPH_JPEG_LIBJPEG)
-        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_LIBJPEG>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_samples);
+        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_LIBJPEG>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_samples, d_refs, d_corr);
     else
-        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_ZUNE>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_samples);
+        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_ZUNE>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_samples, d_refs, d_corr);
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }
@@ -1158,15 +1264,24 @@ int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HIm
     return RPH_OK;
 }
 
-int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const PScan *d_pscans, const uint32_t *d_order, uint32_t n,
-                         const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, unsigned long long *d_masks, uint8_t *d_status)
+int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const PScan *d_pscans, const uint32_t *d_items,
+                         const uint32_t *level_count, uint32_t n_levels, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, unsigned long long *d_masks,
+                         PCorr *d_corr, size_t n_corr, uint8_t *d_status)
 {
-    if (n == 0) return RPH_OK;
-    const dim3 grid((n + 63) / 64);
-    if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
-        hipLaunchKernelGGL(jpeg_prog_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_order, n, d_luts, n_luts, d_coef, d_masks, d_status);
-    else
-        hipLaunchKernelGGL(jpeg_prog_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_order, n, d_luts, n_luts, d_coef, d_masks, d_status);
+    if (n_levels == 0) return RPH_OK;
+    if (n_corr) RPH_HIP_CHECK(hipMemsetAsync(d_corr, 0, n_corr * sizeof(PCorr), stream));
+    uint32_t first = 0;
+    for (uint32_t l = 0; l < n_levels; l++) {  // the scans of a level only read what earlier levels wrote: the launches are the dependencies
+        const uint32_t n = level_count[l];
+        if (n == 0) continue;
+        const dim3 grid((n + 63) / 64);
+        if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
+            hipLaunchKernelGGL(jpeg_prog_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_items + first, n, d_luts, n_luts, d_coef, d_masks, d_corr,
+                               d_status);
+        else
+            hipLaunchKernelGGL(jpeg_prog_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_items + first, n, d_luts, n_luts, d_coef, d_masks, d_corr, d_status);
+        first += n;
+    }
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }

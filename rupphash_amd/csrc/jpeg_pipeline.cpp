@@ -80,8 +80,10 @@ struct Slot {
     size_t res_images = 0;
     uint8_t *d_segwork = nullptr;  // device entropy, segmented streams: states | MCU-start bitmaps | out positions
     size_t segwork_cap = 0;
-    unsigned long long *d_pmask = nullptr;  // device entropy, progressive files: {nonzero, negative} masks, two words per block
+    unsigned long long *d_pmask = nullptr;  // device entropy, progressive files: which coefficients are nonzero, one word per block
     size_t pmask_cap = 0;
+    PCorr *d_pcorr = nullptr;               // and the records of their AC refinement scans (jpeg_device.h)
+    size_t pcorr_cap = 0;
     void release()
     {
         if (stream) (void)hipStreamSynchronize(stream);
@@ -92,6 +94,7 @@ struct Slot {
         res.release();
         if (d_segwork) (void)hipFree(d_segwork);
         if (d_pmask) (void)hipFree(d_pmask);
+        if (d_pcorr) (void)hipFree(d_pcorr);
         if (stream) (void)hipStreamDestroy(stream);
         if (done) (void)hipEventDestroy(done);
         *this = Slot();
@@ -353,6 +356,8 @@ struct ChunkDesc {
     size_t off_planes = 0, off_images = 0, off_tables = 0, off_end = 0;
     std::vector<uint32_t> image_of, plane_of;  // per chunk position: index of its JImage / first JPlane (UINT32_MAX: not decodable)
     uint32_t n_planes = 0, n_images = 0;
+    const PRef *d_refs = nullptr;   // device entropy, progressive files: the AC refinement scans of their planes and the records of
+    const PCorr *d_corr = nullptr;  // their corrections (the IDCT kernel applies them)
 };
 
 // Sub-batch boundaries are where the offsets of planes and pixels restart from 0: `sub_of[r]` = first chunk position of r's sub-batch.
@@ -399,6 +404,9 @@ int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first
             pl.blocks_h = kc.blocks_h;
             pl.qt = D.n_planes;
             pl.pitch = kc.blocks_w * 8;
+            pl.real_bw = kc.real_bw;
+            pl.real_bh = kc.real_bh;
+            pl.ref_first = pl.ref_count = 0;
             memcpy(hq + (size_t)D.n_planes * 64, f.qt[kc.tq], 128);
             im.plane_off[c] = plane_bytes;
             im.pitch[c] = pl.pitch;
@@ -446,7 +454,7 @@ int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, Jobs &jobs, 
     const JPlane *dp = reinterpret_cast<const JPlane *>(S.meta.d + D.off_planes) + p0;
     const JImage *di = reinterpret_cast<const JImage *>(S.meta.d + D.off_images) + i0;
     const uint16_t *dq = reinterpret_cast<const uint16_t *>(S.meta.d + D.off_tables);
-    RPH_TRY(rph_jpeg_launch_idct(flavour, max_blocks, p1 - p0, s, d_coef, dq, dp, P.d_planes[b]));
+    RPH_TRY(rph_jpeg_launch_idct(flavour, max_blocks, p1 - p0, s, d_coef, dq, dp, P.d_planes[b], D.d_refs, D.d_corr));
     RPH_TRY(rph_jpeg_launch_color(flavour, max_groups, i1 - i0, s, P.d_planes[b], di, P.d_out[b]));
     if (!out.want_hash) return RPH_OK;
     // hash runs of equal geometry where the pixels lie (generate_pdq_features, scanner.rs:1410)
@@ -763,8 +771,15 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         std::vector<uint32_t> item_len;
         std::vector<SegFile> seg_files;
         std::vector<PScan> pscans;            // the scans of the chunk's progressive files
-        std::vector<uint32_t> prog_order;     // the progressive files (indices into the chunk), longest first
-        uint64_t prog_blocks = 0;             // their blocks: two mask words each
+        std::vector<uint32_t> prog_order;     // the progressive files (indices into the chunk)
+        std::vector<uint32_t> pscan_level;    // per scan: its depth in the order "needs an earlier scan of the same coefficients" (a launch per depth)
+        std::vector<PRef> prefs;              // their AC refinement scans, grouped by plane (file order within a plane)
+        struct PlaneRefs {
+            uint32_t r, first[3], count[3];
+        };
+        std::vector<PlaneRefs> plane_refs;
+        uint64_t prog_blocks = 0;             // their blocks: one mask word each
+        uint64_t prog_corr = 0;               // records of their AC refinement scans
         uint32_t n_segs = 0;
         items.reserve(m);
         for (size_t i = first; i < last; i++) {
@@ -772,18 +787,43 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             if (j.status == RPH_ERR_UNSUPPORTED || j.status == RPH_ERR_CAPACITY) leftover.push_back(idx[i]);
             if (j.status != RPH_OK) continue;
             const uint32_t r = (uint32_t)(i - first);
-            if (j.frame.progressive) {  // one lane walks all scans of the file (jpeg_prog_kernel)
+            if (j.frame.progressive) {  // one lane per scan (jpeg_prog_kernel)
                 himgs[r].mask_first = (uint32_t)prog_blocks;
                 prog_blocks += j.frame.total_blocks;
                 himgs[r].pscan_first = (uint32_t)pscans.size();
                 himgs[r].pscan_count = (uint32_t)j.plan.prog.size();
+                const size_t p0 = pscans.size();
                 for (const rphj::ScanPlan &sp : j.plan.prog) {
                     PScan ps;
                     ps.off = sp.stream_off, ps.len = sp.stream_len, ps.ns = sp.ns, ps.ss = sp.ss, ps.se = sp.se, ps.ah = sp.ah, ps.al = sp.al;
                     for (int c = 0; c < 3; c++) ps.ci[c] = sp.ci[c], ps.dc[c] = sp.dc[c];
                     ps.ac = sp.ac[0];
+                    ps.image = r;
+                    ps.corr_first = 0;
+                    if (sp.ss > 0 && sp.ah > 0) {
+                        const rphj::Comp &kc = j.frame.comp[sp.ci[0]];
+                        ps.corr_first = (uint32_t)prog_corr;
+                        prog_corr += (uint64_t)kc.real_bw * kc.real_bh;
+                    }
+                    // depth: one more than the deepest earlier scan of this file that shares a component and a coefficient with this one
+                    uint32_t level = 0;
+                    auto comps = [](const PScan &x) { uint32_t m = 0; for (uint32_t c = 0; c < x.ns && c < 3; c++) m |= 1u << x.ci[c]; return m; };
+                    for (size_t q = p0; q < pscans.size(); q++) {
+                        const PScan &e = pscans[q];
+                        if ((comps(e) & comps(ps)) && e.ss <= ps.se && ps.ss <= e.se) level = std::max(level, pscan_level[q] + 1);
+                    }
                     pscans.push_back(ps);
+                    pscan_level.push_back(level);
                 }
+                PlaneRefs pr;
+                pr.r = r;
+                for (uint32_t c = 0; c < 3; c++) {
+                    pr.first[c] = (uint32_t)prefs.size();
+                    for (size_t q = p0; q < pscans.size(); q++)
+                        if (pscans[q].ss > 0 && pscans[q].ah > 0 && pscans[q].ci[0] == c) prefs.push_back(PRef{pscans[q].corr_first, pscans[q].al});
+                    pr.count[c] = (uint32_t)prefs.size() - pr.first[c];
+                }
+                plane_refs.push_back(pr);
                 prog_order.push_back(r);
                 continue;
             }
@@ -818,7 +858,21 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 item_len.push_back(end > off ? end - off : 0);
             }
         }
-        std::stable_sort(prog_order.begin(), prog_order.end(), [&](uint32_t a, uint32_t b) { return jobs[idx[first + a]].len > jobs[idx[first + b]].len; });
+        // the lanes of a launch: the scans of one depth, scans of one kind together (the lanes of a wave run the same loop), longest first
+        std::vector<uint32_t> pitems(pscans.size()), level_count;
+        for (uint32_t t = 0; t < pitems.size(); t++) pitems[t] = t;
+        {
+            auto kind = [&](uint32_t t) { return (pscans[t].ss ? 2u : 0u) + (pscans[t].ah ? 1u : 0u); };
+            std::stable_sort(pitems.begin(), pitems.end(), [&](uint32_t a, uint32_t b) {
+                if (pscan_level[a] != pscan_level[b]) return pscan_level[a] < pscan_level[b];
+                if (kind(a) != kind(b)) return kind(a) > kind(b);  // (refinements of AC bands are the slowest per byte: first)
+                return pscans[a].len > pscans[b].len;
+            });
+            for (uint32_t t : pitems) {
+                if (pscan_level[t] >= level_count.size()) level_count.resize(pscan_level[t] + 1, 0);
+                level_count[pscan_level[t]]++;
+            }
+        }
         std::vector<uint32_t> order(items.size());
         for (uint32_t t = 0; t < order.size(); t++) order[t] = t;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return item_len[a] > item_len[b]; });
@@ -835,7 +889,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         // (the items of the segments exist on the device only: d_meta has room for them, the upload stops before them)
         const size_t off_himg = align_up(recon_bytes, 16), off_order = off_himg + m * sizeof(HImage), off_luts = align_up(off_order + order.size() * 4, 16),
                      off_segf = align_up(off_luts + luts.size() * sizeof(rphj::DeviceLut), 16), off_pscan = align_up(off_segf + seg_files.size() * sizeof(SegFile), 16),
-                     off_porder = off_pscan + pscans.size() * sizeof(PScan), off_items = align_up(off_porder + prog_order.size() * 4, 16),
+                     off_porder = off_pscan + pscans.size() * sizeof(PScan), off_pitems = off_porder + prog_order.size() * 4,
+                     off_prefs = align_up(off_pitems + pitems.size() * 4, 16), off_items = align_up(off_prefs + prefs.size() * sizeof(PRef), 16),
                      upload_bytes = off_items + items.size() * sizeof(HItem), meta_bytes = off_items + (size_t)n_items * sizeof(HItem);
         RPH_TRY(S.meta.reserve(meta_bytes));
         const size_t segwork = align_up((size_t)n_segs * sizeof(SegState), 16) + (size_t)n_segs * (ctx->jpeg_seg_bytes + 12) + 64;
@@ -846,11 +901,18 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             S.segwork_cap = segwork + segwork / 4;
         }
         if (prog_blocks >= ((uint64_t)1 << 32)) return RPH_ERR_CAPACITY;  // (a chunk's coefficients are capped far below: 2^32 blocks are 512 GB)
-        if (prog_blocks && S.pmask_cap < prog_blocks * 16) {
+        if (prog_corr >= ((uint64_t)1 << 32)) return RPH_ERR_CAPACITY;
+        if (prog_corr && S.pcorr_cap < prog_corr * sizeof(PCorr)) {
+            if (S.d_pcorr) (void)hipFree(S.d_pcorr);
+            S.d_pcorr = nullptr, S.pcorr_cap = 0;
+            RPH_HIP_CHECK(hipMalloc((void **)&S.d_pcorr, prog_corr * sizeof(PCorr) + prog_corr * 4));
+            S.pcorr_cap = prog_corr * sizeof(PCorr) + prog_corr * 4;
+        }
+        if (prog_blocks && S.pmask_cap < prog_blocks * 8) {
             if (S.d_pmask) (void)hipFree(S.d_pmask);
             S.d_pmask = nullptr, S.pmask_cap = 0;
-            RPH_HIP_CHECK(hipMalloc((void **)&S.d_pmask, prog_blocks * 16 + prog_blocks * 4));
-            S.pmask_cap = prog_blocks * 16 + prog_blocks * 4;
+            RPH_HIP_CHECK(hipMalloc((void **)&S.d_pmask, prog_blocks * 8 + prog_blocks * 2));
+            S.pmask_cap = prog_blocks * 8 + prog_blocks * 2;
         }
         ChunkDesc D;
         std::vector<size_t> subs;
@@ -863,6 +925,18 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         if (!prog_order.empty()) {
             memcpy(S.meta.h + off_pscan, pscans.data(), pscans.size() * sizeof(PScan));
             memcpy(S.meta.h + off_porder, prog_order.data(), prog_order.size() * 4);
+            memcpy(S.meta.h + off_pitems, pitems.data(), pitems.size() * 4);
+            if (!prefs.empty()) {
+                memcpy(S.meta.h + off_prefs, prefs.data(), prefs.size() * sizeof(PRef));
+                JPlane *hp = reinterpret_cast<JPlane *>(S.meta.h + D.off_planes);
+                for (const PlaneRefs &pr : plane_refs) {
+                    if (D.plane_of[pr.r] == UINT32_MAX) continue;
+                    const int nc = jobs[idx[first + pr.r]].frame.ncomp;
+                    for (int c = 0; c < nc && c < 3; c++) hp[D.plane_of[pr.r] + c].ref_first = pr.first[c], hp[D.plane_of[pr.r] + c].ref_count = pr.count[c];
+                }
+                D.d_refs = reinterpret_cast<const PRef *>(S.meta.d + off_prefs);
+                D.d_corr = S.d_pcorr;
+            }
         }
         // ---- device: streams up, zeroed coefficients, the walk, then reconstruction + hashing sub-batch by sub-batch
         const double t_desc = now_ms();
@@ -894,10 +968,11 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 RPH_TRY(rph_jpeg_launch_walk(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const HItem *>(S.meta.d + off_items),
                                              reinterpret_cast<const uint32_t *>(S.meta.d + off_order), n_ordered, n_items,
                                              reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, R.status));
-            if (prog_blocks) RPH_HIP_CHECK(hipMemsetAsync(S.d_pmask, 0, prog_blocks * 16, s));
+            if (prog_blocks) RPH_HIP_CHECK(hipMemsetAsync(S.d_pmask, 0, prog_blocks * 8, s));
             RPH_TRY(rph_jpeg_launch_prog(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const PScan *>(S.meta.d + off_pscan),
-                                         reinterpret_cast<const uint32_t *>(S.meta.d + off_porder), (uint32_t)prog_order.size(),
-                                         reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, S.d_pmask, R.status));
+                                         reinterpret_cast<const uint32_t *>(S.meta.d + off_pitems), level_count.data(), (uint32_t)level_count.size(),
+                                         reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, S.d_pmask, S.d_pcorr, (size_t)prog_corr,
+                                         R.status));
             lap(t_walk);
             for (size_t q = 0; q < subs.size(); q++) {
                 const size_t r0 = subs[q], r1 = q + 1 < subs.size() ? subs[q + 1] : m;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/jpeg_stage_run.py small|photos [calls] -- the JPEG leg of bench.py as a bare loop of `calls` rph_jpeg_pdq_hash_batch calls, to be run
+"""tools/jpeg_stage_run.py small|photos|prog [calls] -- the JPEG leg of bench.py as a bare loop of `calls` rph_jpeg_pdq_hash_batch calls, to be run
 under rocprofv3 --kernel-trace --stats (tools/jpeg_stage_profile.sh): every kernel launch of the run belongs to the one workload, so a stage's
 time per call is its TotalDurationNs / calls.  Prints one JSON line with the counts the per-stage rooflines are priced with."""
 import io
@@ -39,7 +39,7 @@ else:
     im = Image.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "bench.jpg"))
     im.load()  # (the threads below crop it: decode once, here)
     with ThreadPoolExecutor(threads) as pool:
-        base = list(pool.map(lambda k: enc(np.asarray(im.crop((k % 16, k // 16, k % 16 + 1265, k // 16 + 850))), quality=90, subsampling=2), range(distinct)))
+        base = list(pool.map(lambda k: enc(np.asarray(im.crop((k % 16, k // 16, k % 16 + 1265, k // 16 + 850))), quality=90, subsampling=2, progressive=(kind == "prog")), range(distinct)))
 files = eng.jpeg_file_list([base[k % distinct] for k in range(n)])
 eng.jpeg_set_entropy(1)
 eng.jpeg_pdq_hash_batch(files, threads=threads)  # buffers
