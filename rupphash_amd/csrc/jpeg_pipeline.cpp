@@ -119,7 +119,7 @@ struct Slot {
         return RPH_OK;
     }
 };
-constexpr int JPEG_LANES = 3;  // chunks in flight in the device-entropy pipeline (the host-entropy pipeline uses the first two)
+constexpr int JPEG_LANES = 4;  // chunks in flight in the device-entropy pipeline (the host-entropy pipeline uses the first two)
 struct JpegPipe {
     Slot slot[JPEG_LANES];
     // reconstruction buffers (sample planes, packed pixels) shared by the slots' sub-batches: used in stream order, one sub-batch at a
