@@ -720,6 +720,10 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
     uint32_t bad = 0;
 #ifdef RPH_PROG_TIMING
     const uint64_t t_scan = wall_clock64();
+    uint32_t t_steps = 0;
+#define RPH_PROG_STEP() t_steps++
+#else
+#define RPH_PROG_STEP()
 #endif
     BitR b;
     b.init(streams + im->stream_base + P.off, P.len);
@@ -737,6 +741,7 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
         int p0 = 0, p1 = 0, p2 = 0;
         bool done = MX == 0 || MY == 0;
         while (!done) {
+            RPH_PROG_STEP();
             b.fill();
             const uint32_t Hc = sel3(i, H0, H1, H2), Vc = sel3(i, V0, V1, V2), BWc = sel3(i, BW0, BW1, BW2), FBc = sel3(i, FB0, FB1, FB2);
             const uint64_t base = (img_fb + FBc + (uint64_t)(my * Vc + v) * BWc + (mx * Hc + h)) * 64;
@@ -807,6 +812,7 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
             unsigned long long nz_acc = 0;  // placements in the current block
             const uint64_t max_it = (uint64_t)total * 65 + 8;
             for (uint64_t it = 0; bl < total && it < max_it; it++) {
+                RPH_PROG_STEP();
                 b.fill();
                 const uint32_t rs = b.symbol8(s_look8, lc, s_syms, lane);
                 if (rs > 255) {
@@ -908,6 +914,7 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                         base = (row_base + col) * 64;
                         fresh = false;
                     }
+                    RPH_PROG_STEP();
                     b.fill();
                     uint32_t r = 0;
                     int value = 0;
@@ -979,7 +986,10 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
         }
     }
 #ifdef RPH_PROG_TIMING
-    if (ii == 0) printf("scan ns=%u ss=%u se=%u ah=%u al=%u len=%u: %llu us\n", P.ns, P.ss, P.se, P.ah, P.al, P.len, (unsigned long long)(wall_clock64() - t_scan) / 100);
+    if (ii == 0) {
+        const unsigned long long us = (unsigned long long)(wall_clock64() - t_scan) / 100;
+        printf("scan ns=%u ss=%u se=%u ah=%u al=%u len=%u: %llu us, %u steps of this lane, %.2f us per step\n", P.ns, P.ss, P.se, P.ah, P.al, P.len, us, t_steps, (double)us / (t_steps ? t_steps : 1));
+    }
 #endif
     if (bad) status[ii] = 1;  // (the results were zeroed before the launch; the scans of a file are different lanes)
 }
