@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/jpeg_stage_roofline.py DIR -- {small,photos}_kernel_stats.csv + {small,photos}_counts.json (tools/jpeg_stage_profile.sh) -> per-stage
+"""tools/jpeg_stage_roofline.py DIR -- {small,photos,prog}_kernel_stats.csv + {small,photos,prog}_counts.json (tools/jpeg_stage_profile.sh) -> per-stage
 rooflines of the JPEG path as JSON: algorithmic bytes per call / the stage's kernel time per call / 8 TB/s for the HBM-bound stages (IDCT,
 upsampling + colour, pre-downsample, hash), entropy bytes per second for the Huffman walk (latency-bound: one serial bit stream per lane)."""
 import csv
@@ -10,7 +10,7 @@ import sys
 HBM = 8000.0e9
 d = sys.argv[1]
 out = {}
-for kind in ("small", "photos"):
+for kind in ("small", "photos", "prog"):
     cf = os.path.join(d, f"{kind}_counts.json")
     if not os.path.exists(cf):
         continue
@@ -49,6 +49,12 @@ for kind in ("small", "photos"):
                                   "entropy_GB_per_s": round(c["file_bytes_per_call"] / (walk_ms * 1e-3) / 1e9, 2),
                                   "blocks_per_s": round(blocks / (walk_ms * 1e-3) / 1e9, 3), "blocks_per_s_unit": "G blocks/s",
                                   "coefficient_bytes_zeroed_and_written_per_call": int(blocks * 128)}
+    if ms.get("jpeg_prog_kernel"):
+        pm = ms["jpeg_prog_kernel"]
+        stages["progressive_walk"] = {"kernel": "jpeg_prog_kernel (one lane per scan; one launch per depth of the scans' dependency order, three for libjpeg's script)",
+                                      "ms_per_call": round(pm, 3), "bound": "latency (a lane's dependent instruction chain: ~138 instructions per symbol step, 8.7 clocks each when a wave is alone on its SIMD)",
+                                      "entropy_GB_per_s": round(c["file_bytes_per_call"] / (pm * 1e-3) / 1e9, 2),
+                                      "note": "kernel time summed over the chunks' launches, which overlap pairwise"}
     if sync_ms:
         stages["segment_synchronisation"] = {"kernels": "jpeg_sync_kernel (round 0, validation rounds, count pass) + jpeg_seg_items_kernel", "ms_per_call": round(sync_ms, 3),
                                              "entropy_GB_per_s": round(c["file_bytes_per_call"] / (sync_ms * 1e-3) / 1e9, 2)}
