@@ -77,12 +77,14 @@ struct HItem {
 // ---- a stream WITHOUT restart markers, cut into segments of SEG_BYTES that are walked side by side (jpeg_sync_kernel) ------------------
 // A lane cannot know where a symbol begins in the middle of a stream, but Huffman streams re-synchronise: a lane that starts at a
 // segment boundary in an assumed state (an MCU begins here) soon parses the same symbols as the true decoder.  Round 0: every lane
-// decodes from its segment boundary, marks where it saw MCUs begin inside its segment (bitmap) and reports the first MCU start behind
-// its segment (`out`).  Validation rounds: the entry of segment t is the `out` of segment t - 1; if the lane saw an MCU begin exactly
-// there its results stand, otherwise it decodes again from the entry.  The count pass decodes every segment from its entry once more
-// (MCUs and DC sums per segment, and `out` again); the prefix kernel then checks entry[t] == out[t - 1] along each file -- true for
-// segment 0 by construction, hence for all of them -- and turns the segments into walk items (first MCU, DC predictions); a file
-// that did not settle is walked by one lane as before.  Nothing here is trusted: the chain is verified, or not used.
+// decodes from its segment boundary, records the first MCU starts it saw inside its segment with the DC sums at each of them
+// (SegTable, jpeg_kernels.hip) and reports the first MCU start behind its segment (`out`).  Validation rounds: the entry of segment t is
+// the `out` of segment t - 1.  If that is one of the recorded MCU starts, round 0's decode went through it and everything from there on --
+// MCU count, DC sums, exit -- is in the record; otherwise the lane decodes from the entry until it reaches a recorded MCU start (it is in
+// step with round 0 from there: the rest comes from the record) or the end of the segment.  The prefix kernel then checks
+// entry[t] == out[t - 1] along each file -- true for segment 0 by construction, hence for all of them -- and turns the segments into walk
+// items (first MCU, DC predictions); a file that did not settle is walked by one lane as before.  Nothing here is trusted: the chain is
+// verified, or not used.
 constexpr uint32_t SEG_NONE = 0xFFFFFFFFu;
 struct SegFile {           // one per segmented file of the chunk
     uint32_t image;        // index of its HImage
@@ -96,7 +98,7 @@ struct SegState {          // one per segment
     uint32_t out;          // first MCU start at or behind the end of the segment, as this lane's last decode saw it
     uint32_t count;        // MCUs that begin in [entry, out)
     int32_t dc[3];         // sum of their DC differences per component of the scan
-    uint32_t from;         // the position the lane's last decode started from (its bitmap describes that decode)
+    uint32_t from;         // the position the results below were decoded (or taken from round 0's record) from
     uint32_t out_check;    // count pass: `out` as decoded from `entry` (must equal out)
 };
 
@@ -121,6 +123,7 @@ int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HIm
                          PCorr *d_corr, size_t n_corr, uint8_t *d_status);
 // Segment synchronisation of the files in d_files (see above): round 0, `rounds` validation rounds, the count pass and the prefix
 // kernel, which writes the files' walk items (d_items[first_item ..]) -- n_segs of them per file, or one whole-file item and empty ones
-// when the file's chain did not verify.  d_bitmap: seg_bytes + 12 bytes per segment (marks, two `out` slots, the segment -> file map).
+// when the file's chain did not verify.  d_work: rph_jpeg_segment_work_bytes(n_segs) (round 0's records, two `out` slots per segment, the segment -> file map).
 int rph_jpeg_launch_segments(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const SegFile *d_files, uint32_t n_files, SegState *d_segs,
-                             uint32_t n_segs, uint32_t seg_bytes, uint32_t *d_bitmap, int rounds, const rphj::DeviceLut *d_luts, uint32_t n_luts, HItem *d_items);
+                             uint32_t n_segs, uint32_t seg_bytes, void *d_work, int rounds, const rphj::DeviceLut *d_luts, uint32_t n_luts, HItem *d_items);
+size_t rph_jpeg_segment_work_bytes(uint32_t n_segs);  // of d_work

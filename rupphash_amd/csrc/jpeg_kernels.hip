@@ -996,21 +996,37 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Segments of a stream without restart markers (jpeg_device.h): one lane per segment.  mode 0: decode from the segment boundary as if an
-// MCU began there, mark the MCU starts seen inside the segment, report the first one behind it.  mode 1 (validation round `round`): the
-// entry is the predecessor's `out` of the previous round; if this lane's last decode started there or saw an MCU begin there, its
-// results stand, otherwise it decodes again from the entry.  mode 2: decode from the entry once more, counting MCUs and DC differences.
+// MCU began there, record the MCU starts seen inside the segment (SegTable), report the first one behind it.  mode 1 (validation round
+// `round`): the entry is the predecessor's `out` of the previous round; results that began there stand, an entry that round 0 recorded
+// takes its results from the record, otherwise the lane decodes from the entry until it falls into step with round 0's record.  mode 2:
+// lanes without an entry get empty counts (nothing is decoded any more: every lane with an entry holds results from exactly there).
 // Nothing is written to the coefficient buffer here.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct SegOut2 {
     uint32_t v[2];
 };
+// What round 0 saw from a segment's boundary on.  A later decode of the segment from its true entry falls into step with round 0's
+// after an MCU or two; from the MCU start where they meet, everything round 0 found is the true decode's too.  So round 0 leaves the
+// first SEG_MARKS MCU starts it saw inside the segment with the DC sums at each of them: a validation round whose decode reaches one of
+// them stops there and takes the rest -- MCU count, DC sums, exit -- from this record; an entry that IS one of them needs no decode at all.
+constexpr int SEG_MARKS = 16;
+struct SegTable {
+    uint32_t n;                   // MCU starts recorded (pos[0] = 0: the boundary itself, where round 0 assumed one)
+    uint32_t count;               // MCUs round 0 saw begin in [boundary, out)
+    int32_t dc[3];                // sum of their DC differences per component of the scan
+    uint32_t out;                 // round 0's exit (SEG_NONE: it broke off)
+    uint32_t pos[SEG_MARKS];      // bit offsets from the boundary, ascending; the k-th is where round 0's k-th MCU began
+    int32_t sum[SEG_MARKS][3];    // the DC sums when it began
+    uint32_t pad[2];
+};
+static_assert(sizeof(SegTable) == 288, "segment tables are packed");
 // LDS_TABLES as in the walk: the table probe is on the critical path of every symbol (from global memory it is a cache round trip per symbol:
 // 68 % of this kernel's wave-cycles were spent waiting, profiles/r03_pmc_jpeg_walk_sync.txt).
 constexpr int SYNC_BLOCK = 256;
 template <int LDS_TABLES>
 __global__ void __launch_bounds__(SYNC_BLOCK) jpeg_sync_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const SegFile *__restrict__ files,
                                                        const uint32_t *__restrict__ seg_file, SegState *__restrict__ segs, SegOut2 *__restrict__ outs, uint32_t n_segs,
-                                                       uint32_t seg_bytes, uint32_t *__restrict__ bitmap, int mode, int round, const rphj::DeviceLut *__restrict__ g_luts,
+                                                       uint32_t seg_bytes, SegTable *__restrict__ tables, int mode, int round, const rphj::DeviceLut *__restrict__ g_luts,
                                                        uint32_t n_luts)
 {
     __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
@@ -1023,10 +1039,11 @@ __global__ void __launch_bounds__(SYNC_BLOCK) jpeg_sync_kernel(const uint8_t *__
     const HImage *im = imgs + F.image;
     const HScan *S = &im->scan[0];
     const uint32_t seg_bits = seg_bytes * 8, lo = t * seg_bits, hi = lo + seg_bits, end_bits = S->len * 8;
-    uint32_t *bm = bitmap + (size_t)(u < n_segs ? u : n_segs - 1) * (seg_bytes / 4);
+    SegTable *const tab = tables + (u < n_segs ? u : n_segs - 1);
     SegState st{};
     const int rd = (round + 1) & 1, wr = round & 1;  // validation round r reads the outs of round r - 1 (round 0 wrote slot 0)
-    uint32_t start = 0;
+    uint32_t start = 0, tab_n = 0;
+    uint32_t marks[SEG_MARKS];  // (validation decodes: round 0's MCU starts, as positions of the scan)
     auto prepare = [&]() -> bool {
         if (u >= n_segs) return false;
         st = segs[u];
@@ -1036,16 +1053,38 @@ __global__ void __launch_bounds__(SYNC_BLOCK) jpeg_sync_kernel(const uint8_t *__
         } else if (mode == 1) {
             const uint32_t own = outs[u].v[rd];
             const uint32_t e = t == 0 ? 0 : outs[u - 1].v[rd];
-            outs[u].v[wr] = own;  // unless decoded again below
+            outs[u].v[wr] = own;  // unless this round finds another below
             if (e == SEG_NONE) return false;  // the predecessor has nothing to say yet
             st.entry = e;
             if (e >= hi || e >= end_bits) {  // no MCU begins in this segment (or, in a damaged stream, the predecessor ran past the end of the scan: nothing is decoded from there): pass the position on
                 st.from = e;
+                st.count = 0;
+                st.dc[0] = st.dc[1] = st.dc[2] = 0;
+                st.out_check = e;
                 outs[u].v[wr] = e;
                 segs[u] = st;
                 return false;
             }
-            if (e == st.from || (st.from == lo && e >= lo && ((bm[(e - lo) >> 5] >> ((e - lo) & 31)) & 1u))) {  // the last decode went through e: its `out` stands
+            if (e == st.from) {  // the last decode (or record) began there: its results stand
+                segs[u] = st;
+                return false;
+            }
+            // is the entry one of the MCU starts round 0 recorded?  Then round 0's decode went through it: everything from there on is in the record
+            const uint32_t n = tab->out == SEG_NONE ? 0u : tab->n;
+            tab_n = n < (uint32_t)SEG_MARKS ? n : (uint32_t)SEG_MARKS;
+#pragma unroll
+            for (int k = 0; k < SEG_MARKS; k++) marks[k] = (uint32_t)k < tab_n ? lo + tab->pos[k] : SEG_NONE;
+            uint32_t hit = SEG_NONE;
+#pragma unroll
+            for (int k = 0; k < SEG_MARKS; k++) hit = marks[k] == e ? (uint32_t)k : hit;
+            if (hit != SEG_NONE) {
+                st.from = e;
+                st.count = tab->count - hit;
+                st.dc[0] = tab->dc[0] - tab->sum[hit][0];
+                st.dc[1] = tab->dc[1] - tab->sum[hit][1];
+                st.dc[2] = tab->dc[2] - tab->sum[hit][2];
+                st.out_check = tab->out;
+                outs[u].v[wr] = tab->out;
                 segs[u] = st;
                 return false;
             }
@@ -1058,8 +1097,7 @@ __global__ void __launch_bounds__(SYNC_BLOCK) jpeg_sync_kernel(const uint8_t *__
                 segs[u] = st;
                 return false;
             }
-            // Most lanes decoded from exactly this entry in a validation round (a decode that starts mid-stream is rarely in step by the first
-            // MCU of its segment, so round 1 sent it back to the predecessor's exit): the counts of that decode stand, nothing is decoded again.
+            // (every lane that was given an entry in a validation round holds the results of a decode, or of a record, from exactly there)
             if (st.from == st.entry) return false;
             start = st.entry;
         }
@@ -1106,9 +1144,13 @@ __global__ void __launch_bounds__(SYNC_BLOCK) jpeg_sync_kernel(const uint8_t *__
     uint32_t nblk = nblk0;
     const rphj::DeviceLut *DCc = D0, *ACc = A0;
     bool is_dc = true;
-    uint32_t count = 0, out = SEG_NONE;
+    uint32_t count = 0, out = SEG_NONE, n_marks = 0;
     int dc0 = 0, dc1 = 0, dc2 = 0;
-    if (mode == 0 && start >= lo) bm[(start - lo) >> 5] |= 1u << ((start - lo) & 31);  // (this lane's own words: no atomics needed)
+    if (mode == 0) {  // the boundary itself: where this decode assumes an MCU
+        tab->pos[0] = 0;
+        tab->sum[0][0] = tab->sum[0][1] = tab->sum[0][2] = 0;
+        n_marks = 1;
+    }
     const uint32_t max_it = seg_bits + 70000;  // every symbol takes at least one bit; an MCU is at most 10 blocks of 64 symbols of <= 32 bits
     for (uint32_t it = 0; it < max_it; it++) {
         if (nb < 32) {
@@ -1170,7 +1212,25 @@ __global__ void __launch_bounds__(SYNC_BLOCK) jpeg_sync_kernel(const uint8_t *__
                         out = pos;
                         break;
                     }
-                    if (mode == 0 && pos >= lo) bm[(pos - lo) >> 5] |= 1u << ((pos - lo) & 31);
+                    if (mode == 0) {
+                        if (n_marks < (uint32_t)SEG_MARKS) {  // (pos >= lo: the decode began at lo)
+                            tab->pos[n_marks] = pos - lo;
+                            tab->sum[n_marks][0] = dc0, tab->sum[n_marks][1] = dc1, tab->sum[n_marks][2] = dc2;
+                            n_marks++;
+                        }
+                    } else if (mode == 1) {  // in step with round 0 from here on?  Then the rest is in its record
+                        uint32_t hit = SEG_NONE;
+#pragma unroll
+                        for (int q = 0; q < SEG_MARKS; q++) hit = marks[q] == pos ? (uint32_t)q : hit;
+                        if (hit != SEG_NONE) {
+                            count += tab->count - hit;
+                            dc0 += tab->dc[0] - tab->sum[hit][0];
+                            dc1 += tab->dc[1] - tab->sum[hit][1];
+                            dc2 += tab->dc[2] - tab->sum[hit][2];
+                            out = tab->out;
+                            break;
+                        }
+                    }
                 }
                 nblk = sel3(i, nblk0, nblk1, nblk2);
                 DCc = sel3(i, D0, D1, D2);
@@ -1184,6 +1244,12 @@ __global__ void __launch_bounds__(SYNC_BLOCK) jpeg_sync_kernel(const uint8_t *__
     st.dc[0] = dc0, st.dc[1] = dc1, st.dc[2] = dc2;
     st.out_check = out;
     if (mode != 2) outs[u].v[mode == 0 ? 0 : wr] = out;
+    if (mode == 0) {
+        tab->n = n_marks;
+        tab->count = count;
+        tab->dc[0] = dc0, tab->dc[1] = dc1, tab->dc[2] = dc2;
+        tab->out = out;
+    }
     segs[u] = st;
 }
 
@@ -1296,24 +1362,27 @@ int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HIm
     return RPH_OK;
 }
 
+size_t rph_jpeg_segment_work_bytes(uint32_t n_segs) { return (size_t)n_segs * (sizeof(SegTable) + sizeof(SegOut2) + 4) + 64; }
+
 int rph_jpeg_launch_segments(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const SegFile *d_files, uint32_t n_files, SegState *d_segs,
-                             uint32_t n_segs, uint32_t seg_bytes, uint32_t *d_bitmap, int rounds, const rphj::DeviceLut *d_luts, uint32_t n_luts, HItem *d_items)
+                             uint32_t n_segs, uint32_t seg_bytes, void *d_work, int rounds, const rphj::DeviceLut *d_luts, uint32_t n_luts, HItem *d_items)
 {
     if (n_files == 0 || n_segs == 0) return RPH_OK;
-    // d_bitmap: n_segs * seg_bytes of marks, then n_segs double-buffered `out` positions, then the segment -> file map
-    SegOut2 *d_outs = reinterpret_cast<SegOut2 *>(reinterpret_cast<uint8_t *>(d_bitmap) + (size_t)n_segs * seg_bytes);
+    // d_work: n_segs records of round 0 (SegTable), then n_segs double-buffered `out` positions, then the segment -> file map
+    SegTable *d_tables = reinterpret_cast<SegTable *>(d_work);
+    SegOut2 *d_outs = reinterpret_cast<SegOut2 *>(d_tables + n_segs);
     uint32_t *d_seg_file = reinterpret_cast<uint32_t *>(d_outs + n_segs);
     hipLaunchKernelGGL(jpeg_seg_map_kernel, dim3((n_files + 63) / 64), dim3(64), 0, stream, d_files, n_files, d_seg_file);
-    RPH_HIP_CHECK(hipMemsetAsync(d_bitmap, 0, (size_t)n_segs * seg_bytes, stream));
+    RPH_HIP_CHECK(hipMemsetAsync(d_tables, 0, (size_t)n_segs * sizeof(SegTable), stream));  // (n = 0: a lane that never ran left no record)
     RPH_HIP_CHECK(hipMemsetAsync(d_outs, 0xFF, (size_t)n_segs * sizeof(SegOut2), stream));
     RPH_HIP_CHECK(hipMemsetAsync(d_segs, 0xFF, (size_t)n_segs * sizeof(SegState), stream));
     const dim3 grid((n_segs + SYNC_BLOCK - 1) / SYNC_BLOCK);
     auto sync = [&](int mode, int round) {
         if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
-            hipLaunchKernelGGL(jpeg_sync_kernel<HUFF_LDS_TABLES>, grid, dim3(SYNC_BLOCK), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_bitmap,
+            hipLaunchKernelGGL(jpeg_sync_kernel<HUFF_LDS_TABLES>, grid, dim3(SYNC_BLOCK), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_tables,
                                mode, round, d_luts, n_luts);
         else
-            hipLaunchKernelGGL(jpeg_sync_kernel<0>, grid, dim3(SYNC_BLOCK), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_bitmap, mode, round,
+            hipLaunchKernelGGL(jpeg_sync_kernel<0>, grid, dim3(SYNC_BLOCK), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_tables, mode, round,
                                d_luts, n_luts);
     };
     sync(0, 0);

@@ -78,7 +78,7 @@ struct Slot {
     Twin meta;              // descriptors (planes | images | tables | HImage | order | DeviceLut)
     Twin res;               // results
     size_t res_images = 0;
-    uint8_t *d_segwork = nullptr;  // device entropy, segmented streams: states | MCU-start bitmaps | out positions
+    uint8_t *d_segwork = nullptr;  // device entropy, segmented streams: states | records of round 0 | out positions | segment -> file map
     size_t segwork_cap = 0;
     unsigned long long *d_pmask = nullptr;  // device entropy, progressive files: which coefficients are nonzero, one word per block
     size_t pmask_cap = 0;
@@ -893,7 +893,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                      off_prefs = align_up(off_pitems + pitems.size() * 4, 16), off_items = align_up(off_prefs + prefs.size() * sizeof(PRef), 16),
                      upload_bytes = off_items + items.size() * sizeof(HItem), meta_bytes = off_items + (size_t)n_items * sizeof(HItem);
         RPH_TRY(S.meta.reserve(meta_bytes));
-        const size_t segwork = align_up((size_t)n_segs * sizeof(SegState), 16) + (size_t)n_segs * (ctx->jpeg_seg_bytes + 12) + 64;
+        const size_t segwork = align_up((size_t)n_segs * sizeof(SegState), 16) + rph_jpeg_segment_work_bytes(n_segs);
         if (n_segs && S.segwork_cap < segwork) {
             if (S.d_segwork) (void)hipFree(S.d_segwork);
             S.d_segwork = nullptr, S.segwork_cap = 0;
@@ -956,9 +956,9 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             lap(t_up);
             if (n_segs) {  // streams without markers: their segments find their entries and become walk items
                 SegState *d_segs = reinterpret_cast<SegState *>(S.d_segwork);
-                uint32_t *d_bitmap = reinterpret_cast<uint32_t *>(S.d_segwork + align_up((size_t)n_segs * sizeof(SegState), 16));
+                void *d_segtab = S.d_segwork + align_up((size_t)n_segs * sizeof(SegState), 16);
                 RPH_TRY(rph_jpeg_launch_segments(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const SegFile *>(S.meta.d + off_segf),
-                                                 (uint32_t)seg_files.size(), d_segs, n_segs, ctx->jpeg_seg_bytes, d_bitmap, 8,
+                                                 (uint32_t)seg_files.size(), d_segs, n_segs, ctx->jpeg_seg_bytes, d_segtab, 8,
                                                  reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), reinterpret_cast<HItem *>(S.meta.d + off_items)));
             }
             lap(t_seg);
