@@ -110,6 +110,8 @@ int rph_jpeg_launch_idct(int flavour, uint32_t max_blocks, uint32_t n_planes, hi
                          uint8_t *d_samples, const PRef *d_refs = nullptr, const PCorr *d_corr = nullptr);
 int rph_jpeg_launch_color(int flavour, uint32_t max_groups, uint32_t n_images, hipStream_t stream, const uint8_t *d_samples, const JImage *d_images, uint8_t *d_pixels);
 // d_order: the first n_ordered items in the order the lanes take them (longest first); items n_ordered .. n_items - 1 are taken as they lie
+// A launch of that many items builds every block in LDS and writes it out whole (zeros included): blocks the walk covers need no zeroing before.
+bool rph_jpeg_walk_writes_whole_blocks(uint32_t n_items);
 int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const HItem *d_items, const uint32_t *d_order, uint32_t n_ordered,
                          uint32_t n_items, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status);
 // Progressive files, one SCAN per lane.  A scan depends on the earlier scans of its file that touch the same coefficients of the same

@@ -396,23 +396,53 @@ __device__ __forceinline__ T sel3(uint32_t i, T a, T b, T c)
 // LDS_TABLES > 0: the chunk has at most that many distinct Huffman tables (a photo collection usually has the four Annex K tables) and
 // every wave keeps a copy in LDS: the table lookup is on the critical path of every symbol, and an LDS read returns in a tenth of the
 // time of a cached global read.
-template <int LDS_TABLES>
-__global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const HItem *__restrict__ items,
+// STAGE_WAVES > 0: the workgroup has that many waves, which share the copy of the tables, and every lane builds its current block in LDS and
+// writes it out whole when the block is complete -- eight 16-byte stores of its own 128-byte line instead of a 2-byte store per coefficient
+// into 64 different lines per instruction.  That is what the launches with many lanes (segments, restart intervals) are bound by: per
+// chunk of 2 M segment lanes the walk takes 27.7 ms, 16.9 ms with the stores removed (and 45 against 10.5 ms at twice the occupancy: the
+// partly written lines of 1 024 lanes per CU do not fit the L2).
+template <int LDS_TABLES, int STAGE_WAVES>
+__global__ void __launch_bounds__(STAGE_WAVES > 0 ? STAGE_WAVES * 64 : 64) jpeg_huff_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs,
+                                                       const HItem *__restrict__ items,
                                                        const uint32_t *__restrict__ order, uint32_t n_ordered, uint32_t n, const rphj::DeviceLut *__restrict__ g_luts,
                                                        uint32_t n_luts, int16_t *__restrict__ coef, uint8_t *__restrict__ status)
 {
+    constexpr uint32_t THREADS = STAGE_WAVES > 0 ? STAGE_WAVES * 64 : 64;
     __shared__ uint8_t zz[80];
     __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
-    for (int t = threadIdx.x; t < 80; t += 64) zz[t] = c_zigzag[t];
+    __shared__ uint4 s_blk[STAGE_WAVES > 0 ? 8 * THREADS : 1];  // [row of the block][thread]: the lane's block, natural order
+    for (uint32_t t = threadIdx.x; t < 80; t += THREADS) zz[t] = c_zigzag[t];
     if (LDS_TABLES > 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(g_luts);
         uint4 *dst = reinterpret_cast<uint4 *>(s_luts);
         const uint32_t words = n_luts * (uint32_t)(sizeof(rphj::DeviceLut) / 16);
-        for (uint32_t t = threadIdx.x; t < words; t += 64) dst[t] = src[t];
+        for (uint32_t t = threadIdx.x; t < words; t += THREADS) dst[t] = src[t];
     }
+    if (STAGE_WAVES > 0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) s_blk[r * THREADS + threadIdx.x] = make_uint4(0, 0, 0, 0);
+    }
+    // the lane's coefficient n of its current block (natural order): row n >> 3 of s_blk, half-word n & 7
+    int16_t *const my_blk = reinterpret_cast<int16_t *>(s_blk + threadIdx.x);
+    auto put = [&](uint64_t base, uint32_t nat, int16_t v) {
+        if (STAGE_WAVES > 0)
+            my_blk[(nat >> 3) * (THREADS * 8) + (nat & 7)] = v;
+        else
+            coef[base + nat] = v;
+    };
+    auto flush = [&](uint64_t base) {  // the finished block goes out as one line, and the lane's LDS block is empty again
+        if (STAGE_WAVES > 0) {
+            uint4 *dst = reinterpret_cast<uint4 *>(coef + base);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                dst[r] = s_blk[r * THREADS + threadIdx.x];
+                s_blk[r * THREADS + threadIdx.x] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
     const rphj::DeviceLut *luts = LDS_TABLES > 0 ? s_luts : g_luts;
     __syncthreads();
-    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t slot = blockIdx.x * THREADS + threadIdx.x;
     if (slot >= n) return;
     const HItem item = items[slot < n_ordered ? order[slot] : slot];  // the first n_ordered items longest first; the segments' items behind them as they lie
     const uint32_t ii = item.image;
@@ -517,14 +547,14 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
                 p0 = i == 0 ? pv : p0;
                 p1 = i == 1 ? pv : p1;
                 p2 = i == 2 ? pv : p2;
-                coef[base] = (int16_t)pv;
+                put(base, 0, (int16_t)pv);
                 k = 1;
                 is_dc = false;
             } else if (s == 0) {
                 k = r == 15 ? k + 16 : 64;  // ZRL, or end of block
             } else {
                 k += r;
-                coef[base + zz[k < 79 ? k : 79]] = (int16_t)val;
+                put(base, zz[k < 79 ? k : 79], (int16_t)val);
                 k++;
             }
             if (k > 64) {  // a run or ZRL stepped past coefficient 63: the file is damaged (the host decoder's rule, jpeg_host.cpp: kk > 64)
@@ -532,6 +562,7 @@ __global__ void __launch_bounds__(64) jpeg_huff_kernel(const uint8_t *__restrict
                 break;
             }
             if (k >= 64) {  // next block
+                flush(base);
                 is_dc = true;
                 k = 0;
                 if (++h == Hc) {
@@ -1327,15 +1358,34 @@ int rph_jpeg_launch_color(int flavour, uint32_t max_groups, uint32_t n_images, h
     return RPH_OK;
 }
 
+bool rph_jpeg_walk_writes_whole_blocks(uint32_t n_items)
+{
+    static const int stage_env = getenv("RPH_JPEG_WALK_STAGE") ? atoi(getenv("RPH_JPEG_WALK_STAGE")) : -1;  // experiments: 0 never, 1 always
+    return stage_env >= 0 ? stage_env != 0 : n_items >= 262144u;
+}
+
 int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const HItem *d_items, const uint32_t *d_order, uint32_t n_ordered,
                          uint32_t n_items, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status)
 {
-    const dim3 grid((n_items + 63) / 64);
-    if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
-        hipLaunchKernelGGL(jpeg_huff_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, stream, d_streams, d_images, d_items, d_order, n_ordered, n_items, d_luts, n_luts, d_coef,
+    // Many lanes (segments, restart intervals: the launch is bound by its stores) build their blocks in LDS; a launch of a lane per file
+    // is bound by the length of its longest lane and keeps the lighter loop.
+    const bool stage = rph_jpeg_walk_writes_whole_blocks(n_items);
+    auto launch = [&](auto kernel, uint32_t threads) {
+        hipLaunchKernelGGL(kernel, dim3((n_items + threads - 1) / threads), dim3(threads), 0, stream, d_streams, d_images, d_items, d_order, n_ordered, n_items, d_luts, n_luts, d_coef,
                            d_status);
-    else
-        hipLaunchKernelGGL(jpeg_huff_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_items, d_order, n_ordered, n_items, d_luts, n_luts, d_coef, d_status);
+    };
+    if (stage) {
+        if (n_luts <= 4)
+            launch(jpeg_huff_kernel<4, 8>, 512);  // 9.8 + 64 KB of LDS: two workgroups, sixteen waves per CU (75.9 k photos/s; four waves 70.6 k, two 74.0 k)
+        else if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
+            launch(jpeg_huff_kernel<HUFF_LDS_TABLES, 4>, 256);  // 19.6 + 32 KB: twelve waves per CU (71.3 k with these tables; two waves 68.8 k, six 66.4 k, eight 66.9 k)
+        else
+            launch(jpeg_huff_kernel<0, 8>, 512);
+    } else if (n_luts <= (uint32_t)HUFF_LDS_TABLES) {
+        launch(jpeg_huff_kernel<HUFF_LDS_TABLES, 0>, 64);
+    } else {
+        launch(jpeg_huff_kernel<0, 0>, 64);
+    }
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }

@@ -781,6 +781,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         uint64_t prog_blocks = 0;             // their blocks: one mask word each
         uint64_t prog_corr = 0;               // records of their AC refinement scans
         uint32_t n_segs = 0;
+        bool all_one_scan = true;  // every sequential file of the chunk has one scan: its MCUs cover all blocks of its components
         items.reserve(m);
         for (size_t i = first; i < last; i++) {
             Job &j = jobs[idx[i]];
@@ -827,6 +828,9 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 prog_order.push_back(r);
                 continue;
             }
+            if (j.plan.n_scans != 1 || j.plan.scan[0].ns != j.frame.ncomp) all_one_scan = false;
+            if (j.frame.ncomp == 1 && (j.frame.comp[0].blocks_w != j.frame.comp[0].real_bw || j.frame.comp[0].blocks_h != j.frame.comp[0].real_bh))
+                all_one_scan = false;  // (a one-component scan walks the real blocks only: a padded grid keeps its zeroing)
             if (j.marks.empty()) {
                 const rphj::ScanPlan &sp0 = j.plan.scan[0];
                 if (use_segments && j.plan.n_scans == 1 && sp0.restart_interval == 0 && sp0.stream_len >= ctx->jpeg_seg_min_bytes && sp0.stream_len < ((uint32_t)1 << 28)) {
@@ -962,7 +966,10 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                                                  reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), reinterpret_cast<HItem *>(S.meta.d + off_items)));
             }
             lap(t_seg);
-            RPH_HIP_CHECK(hipMemsetAsync(d_coef, 0, blocks * 128, s));
+            // The coefficients start from zero -- unless the walk writes whole blocks and covers every block of the chunk: sequential files of
+            // one scan (interleaved, or one component), no progressive file.  (A file whose walk breaks off is reported as damaged; what its
+            // remaining blocks hold is not looked at.)
+            if (!(rph_jpeg_walk_writes_whole_blocks(n_items) && all_one_scan && prog_order.empty())) RPH_HIP_CHECK(hipMemsetAsync(d_coef, 0, blocks * 128, s));
             lap(t_zero);
             if (n_items)
                 RPH_TRY(rph_jpeg_launch_walk(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const HItem *>(S.meta.d + off_items),
