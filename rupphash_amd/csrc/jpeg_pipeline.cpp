@@ -532,6 +532,7 @@ int run_host_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, const std::vector<ui
     };
     const size_t n = idx.size();
     int k = 0;
+    RPH_JPEG_STAMP("buffers ready");
     for (size_t first = 0; first < n; k++) {
         size_t last = first, blocks = 0;
         while (last < n && last - first < CHUNK_MAX_IMAGES) {
@@ -612,7 +613,15 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                        std::vector<uint32_t> &leftover)
 {
     // images of similar stream length share a wave: sort the whole list by file length first (chunks then are slices of it)
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return jobs[a].len > jobs[b].len; });
+    {  // (keys side by side: sorting through the job records themselves took 22 ms per 100 000 files)
+        std::vector<std::pair<uint64_t, uint32_t>> key(idx.size());
+        for (size_t i = 0; i < idx.size(); i++) key[i] = {~(uint64_t)jobs[idx[i]].len, (uint32_t)i};  // longest first, equal lengths as they came
+        std::sort(key.begin(), key.end());
+        std::vector<uint32_t> sorted(idx.size());
+        for (size_t i = 0; i < idx.size(); i++) sorted[i] = idx[key[i].second];
+        idx.swap(sorted);
+    }
+    RPH_JPEG_STAMP("files sorted by length");
     // the chunk's coefficient buffer: as much of the free device memory as is reasonable, but no more than this call can use
     size_t need = 0;
     for (uint32_t g : idx) need += (size_t)jobs[g].frame.total_blocks * 128;
@@ -684,6 +693,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     }
     const size_t n = idx.size();
     int k = 0;
+    RPH_JPEG_STAMP("buffers ready");
     for (size_t first = 0; first < n; k++) {
         size_t last = first, blocks = 0, file_bytes = 0;
         while (last < n) {
@@ -723,6 +733,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         }
         TableStore store;
         std::vector<HImage> himgs(m);
+        RPH_JPEG_STAMP("lane %d: chunk %d laid out", b, k);
         parallel_for(first, last, threads, [&](size_t i) {
             Job &j = jobs[idx[i]];
             HImage &hi = himgs[i - first];
