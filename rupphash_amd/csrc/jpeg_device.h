@@ -15,9 +15,10 @@ struct JPlane {            // one per component of each decoded image
     uint32_t real_bw, real_bh;      // progressive files walked on the device: the component's real blocks (its AC scans cover those) ...
     uint32_t ref_first, ref_count;  // ... and its AC refinement scans, file order, in the chunk's PRef array: their corrections are added here
 };
-struct PRef {  // an AC refinement scan of a plane: its correction records (PCorr, one per real block, raster order) and its bit
-    uint32_t corr_first, al;
+struct PRef {  // a refinement scan of a plane and its bit.  AC: its correction records (PCorr, one per real block, raster order).  DC
+    uint32_t corr_first, al;  // (al has PREF_DC set): its bits, one byte per block of the padded grid (the walk never touches a coefficient twice)
 };
+constexpr uint32_t PREF_DC = 0x100u;
 struct JImage {
     uint64_t plane_off[3];  // sample planes (Y, Cb, Cr)
     uint64_t out_off;       // packed pixels
@@ -47,14 +48,20 @@ struct HImage {
     uint32_t pscan_first, pscan_count;  // progressive files: their scans in the chunk's PScan array (n_scans = 0)
     uint32_t mask_first, pad_;          // progressive files: index of the file's first block in the chunk's mask array (one 64-bit word per block)
 };
+constexpr uint32_t PSCAN_NONE = 0xFFFFFFFFu;
 struct PScan {  // one scan of a progressive file (T.81 G.1): DC scans (ss == 0) may interleave components, AC scans have one
     uint32_t off, len;       // de-stuffed entropy bytes, from the image's stream_base
     uint32_t ns, ss, se, ah, al;
     uint32_t ci[3], dc[3];   // components (indices into HImage::comp) and their DC tables (first DC scans only)
     uint32_t ac;             // AC table (AC scans)
     uint32_t image;          // index of the file's HImage
+    uint32_t chase[2];       // AC scans: up to two earlier AC scans of the component (indices into the chunk's PScan array, PSCAN_NONE: none)
+                             // that this one follows block by block -- it may read the history of a block once they are past it
+    uint32_t wait_first, wait_count;  // the scans that must have ended before this one begins (a range of the chunk's wait list)
     uint32_t corr_first;     // AC refinement scans: index of the scan's first record in the chunk's correction array (one per block of the
                              // component, raster order over its real blocks)
+    uint32_t dcb[3];         // DC refinement scans: per component of the scan, where its bits go in the chunk's DC bit array (one byte per
+                             // block, the component's padded grid in raster order)
 };
 // What an AC refinement scan leaves per block instead of touching the coefficients with history: which positions of the band (zigzag
 // order = bit number) had history when the scan ran, and their correction bits, the bit of the lowest position lowest.  The IDCT kernel
@@ -107,22 +114,24 @@ constexpr int HUFF_LDS_TABLES = 8;  // the walk keeps the chunk's Huffman tables
 
 // jpeg_kernels.hip: all asynchronous on `stream`; flavour = RPH_JPEG_ZUNE / RPH_JPEG_LIBJPEG
 int rph_jpeg_launch_idct(int flavour, uint32_t max_blocks, uint32_t n_planes, hipStream_t stream, const int16_t *d_coef, const uint16_t *d_tables, const JPlane *d_planes,
-                         uint8_t *d_samples, const PRef *d_refs = nullptr, const PCorr *d_corr = nullptr);
+                         uint8_t *d_samples, const PRef *d_refs = nullptr, const PCorr *d_corr = nullptr, const uint8_t *d_dcbits = nullptr);
 int rph_jpeg_launch_color(int flavour, uint32_t max_groups, uint32_t n_images, hipStream_t stream, const uint8_t *d_samples, const JImage *d_images, uint8_t *d_pixels);
 // d_order: the first n_ordered items in the order the lanes take them (longest first); items n_ordered .. n_items - 1 are taken as they lie
 // A launch of that many items builds every block in LDS and writes it out whole (zeros included): blocks the walk covers need no zeroing before.
 bool rph_jpeg_walk_writes_whole_blocks(uint32_t n_items);
 int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const HItem *d_items, const uint32_t *d_order, uint32_t n_ordered,
                          uint32_t n_items, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, uint8_t *d_status);
-// Progressive files, one SCAN per lane.  A scan depends on the earlier scans of its file that touch the same coefficients of the same
-// component (a refinement on the first scan of its band, the second refinement on the first); the host gives every scan its depth in
-// that order (`level`), and the scans of one level -- of all files -- are walked side by side, level after level (one launch each).
-// d_items: indices into d_pscans, level by level (level_count[l] of them), within a level in the order the lanes take them.
+// Progressive files, one SCAN per lane, all scans of the chunk in one launch.  A scan depends on the earlier scans of its file that touch
+// the same coefficients of the same component.  d_items: indices into d_pscans (PSCAN_NONE: idle lane), 64 per wave, a scan's producers in
+// earlier waves than the scan itself: workgroups start in the order of the grid, so a producer is running (or done) whenever its
+// consumer waits for it.  Every scan publishes how far it has come (d_progress: one zeroed word per scan: blocks done for AC scans, all ones
+// at the end), and a consumer waits on those words -- at its start for the scans of its wait
+// list, before every group of blocks for the scans it follows.
 // d_masks: one zeroed 64-bit word per block of the progressive files (HImage::mask_first): which coefficients are nonzero.
 // d_corr: the correction records of the AC refinement scans (n_corr of them, zeroed here), which rph_jpeg_launch_idct applies.
-int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const PScan *d_pscans, const uint32_t *d_items,
-                         const uint32_t *level_count, uint32_t n_levels, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, unsigned long long *d_masks,
-                         PCorr *d_corr, size_t n_corr, uint8_t *d_status);
+int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const PScan *d_pscans, uint32_t n_pscans, const uint32_t *d_items,
+                         uint32_t n_items, const uint32_t *d_waits, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, unsigned long long *d_masks,
+                         uint32_t *d_progress, PCorr *d_corr, size_t n_corr, uint8_t *d_dcbits, size_t n_dcbits, uint8_t *d_status);
 // Segment synchronisation of the files in d_files (see above): round 0, `rounds` validation rounds, the count pass and the prefix
 // kernel, which writes the files' walk items (d_items[first_item ..]) -- n_segs of them per file, or one whole-file item and empty ones
 // when the file's chain did not verify.  d_work: rph_jpeg_segment_work_bytes(n_segs) (round 0's records, two `out` slots per segment, the segment -> file map).

@@ -162,7 +162,8 @@ __device__ constexpr int unzigzag(int n)
 // correction bit is set moves away from zero by 1 << Al, unless that bit of it is set already (a damaged stream).
 template <int FL>
 __global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t *__restrict__ coef, const uint16_t *__restrict__ qts, const JPlane *__restrict__ planes,
-                                                        uint8_t *__restrict__ out, const PRef *__restrict__ refs, const PCorr *__restrict__ corr)
+                                                        uint8_t *__restrict__ out, const PRef *__restrict__ refs, const PCorr *__restrict__ corr,
+                                                        const uint8_t *__restrict__ dcbits)
 {
     const JPlane pl = planes[blockIdx.y];
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
@@ -181,9 +182,14 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t *__restric
             c[8 * y + 2 * i + 1] = (int32_t)(int16_t)(u[i] >> 16);
         }
     }
-    if (pl.ref_count && bx < pl.real_bw && by < pl.real_bh) {
+    if (pl.ref_count) {
         for (uint32_t q = 0; q < pl.ref_count; q++) {
             const PRef rf = refs[pl.ref_first + q];
+            if (rf.al & PREF_DC) {  // a DC refinement scan: its bit of the block, if set, is the coefficient's bit Al (T.81 G.1.2.1)
+                if (dcbits[(size_t)rf.corr_first + b]) c[0] |= 1 << (rf.al & 31u);
+                continue;
+            }
+            if (bx >= pl.real_bw || by >= pl.real_bh) continue;
             const PCorr rc = corr[(size_t)rf.corr_first + by * pl.real_bw + bx];
             if (rc.bits == 0) continue;
             const unsigned long long dep = deposit64(rc.bits, rc.history);
@@ -616,8 +622,10 @@ __global__ void __launch_bounds__(STAGE_WAVES > 0 ? STAGE_WAVES * 64 : 64) jpeg_
 // and records whatever a damaged stream says.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct LongCodes {  // of one Huffman table: exclusive upper bounds of the codes of 9..16 bits in a 16-bit window; symbol index = (window >> (16 - length)) + delta[length],
-    int32_t maxc[8], dlt[8];  // dlt[0] = delta[9], dlt[j] = delta[9 + j] - delta[8 + j]: the bounds grow with the length, so the reached ones add up to delta[length]
+    int32_t maxc[8], dlt[8];  // dlt[0] = delta[9] - n_short, dlt[j] = delta[9 + j] - delta[8 + j]: the bounds grow with the length, so the reached ones add up to delta[length] - n_short
+    uint32_t n_short;         // codes of up to 8 bits = index of the first longer code's symbol
 };
+constexpr int PROG_LONG_SYMS = 48;  // symbols of codes longer than 8 bits a progressive lane keeps in LDS
 struct BitR {
     const uint8_t *sbase;
     uint32_t limit, q0n, woff;
@@ -671,7 +679,7 @@ struct BitR {
     // ([prefix * 64 + lane]; 0 = longer code) and the symbols (syms: [index * 64 + lane]); for the longer codes the canonical arrays in
     // registers (the bounds grow with the length, so the length is 9 + the number of bounds the window has reached).  With the long codes
     // left in memory nearly every step of a wave paid for one: each lane meets one only every few dozen symbols, but one lane in 64 is enough.
-    __device__ __forceinline__ uint32_t symbol8(const uint16_t *look8, const LongCodes &lc, const uint8_t *syms, uint32_t lane)
+    __device__ __forceinline__ uint32_t symbol8(const uint16_t *look8, const LongCodes &lc, const uint8_t *long_syms, const uint8_t *all_syms, uint32_t lane)
     {
         const uint32_t e = look8[(uint32_t)(acc >> 56) * 64 + lane];
         uint32_t len, sym;
@@ -690,7 +698,10 @@ struct BitR {
             }
             if (over == 8) return 0x100;
             len = 9 + over;
-            sym = syms[((uint32_t)((win >> (16 - len)) + d) & 255) * 64 + lane];
+            // (dlt[0] has the number of shorter codes taken off: the index counts from the first code of nine bits, whose symbols lie in LDS --
+            // the first PROG_LONG_SYMS of them, the likeliest; a table with more long codes reads the rest from memory)
+            const uint32_t at = (uint32_t)((win >> (16 - len)) + d) & 255u;
+            sym = at < (uint32_t)PROG_LONG_SYMS ? long_syms[at * 64 + lane] : all_syms[(at + lc.n_short) & 255u];
         }
         acc <<= len;
         nb -= (int)len;
@@ -717,20 +728,49 @@ struct BitR {
     }
 };
 
-constexpr int PROG_GROUP = 16;  // blocks of history an AC refinement lane holds in LDS at a time
+constexpr int PROG_GROUP = 8;  // blocks of history an AC refinement lane holds in LDS at a time
+
+// How far a scan has come, for the scans that follow it (jpeg_device.h): published by all lanes of a wave together, every PROG_PUBLISH
+// steps.  Everything a following scan reads of this one inside the launch -- the mask words -- is written with device-scope atomics and
+// read with device-scope atomic loads, which meet at the device's point of coherence, not in a cache of their own: what has to be
+// ordered is only "the atomics before, then the progress word", and waiting for the outstanding memory operations does that (a
+// workgroup-scope release: a device-scope one would also write back the whole L2 of the XCD -- at every publication of every wave).
+constexpr uint32_t PROG_PUBLISH = 256;
+__device__ __forceinline__ void prog_publish(uint32_t *progress, uint32_t me, uint32_t done)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(progress + me, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// All lanes of the wave wait until the scans they depend on have come at least as far as they need (NONE: no such scan).  The producers
+// are in workgroups that started before this one; should one never arrive all the same, the wait ends after a few seconds and the
+// file is reported as damaged rather than hanging the device.  (The mask loads that follow are issued after the progress words have
+// come back, and they are device-scope atomic loads.)
+__device__ __forceinline__ bool prog_wait(const uint32_t *progress, uint32_t dep0, uint32_t dep1, uint32_t need)
+{
+    bool ok = false;
+    for (uint32_t spin = 0; spin < (1u << 22); spin++) {
+        ok = (dep0 == PSCAN_NONE || __hip_atomic_load(progress + dep0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) &&
+             (dep1 == PSCAN_NONE || __hip_atomic_load(progress + dep1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need);
+        if (__all((int)ok)) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
+}
 
 template <int LDS_TABLES>
 __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const PScan *__restrict__ pscans,
-                                                       const uint32_t *__restrict__ items, uint32_t n, const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts,
-                                                       int16_t *__restrict__ coef, unsigned long long *__restrict__ masks, PCorr *__restrict__ corr,
-                                                       uint8_t *__restrict__ status)
+                                                       const uint32_t *__restrict__ items, uint32_t n, const uint32_t *__restrict__ waits,
+                                                       const rphj::DeviceLut *__restrict__ g_luts, uint32_t n_luts,
+                                                       int16_t *__restrict__ coef, unsigned long long *__restrict__ masks, uint32_t *__restrict__ progress,
+                                                       PCorr *__restrict__ corr, uint8_t *__restrict__ dcbits, uint8_t *__restrict__ status)
 {
     __shared__ uint8_t zz[80];
     __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
     // the AC table of the lane's scan as an 8-bit lookup of its own: progressive files carry tables optimised per scan, so a chunk has
     // thousands of distinct ones and they stay in global memory -- a probe there is ~1 us on the critical path of every symbol
     __shared__ uint16_t s_look8[256 * 64];
-    __shared__ uint8_t s_syms[256 * 64];
+    __shared__ uint8_t s_syms[PROG_LONG_SYMS * 64];  // the symbols of the first codes of 9..16 bits
     __shared__ unsigned long long s_ring[PROG_GROUP * 64];
     for (int t = threadIdx.x; t < 80; t += 64) zz[t] = c_zigzag[t];
     if (LDS_TABLES > 0) {
@@ -743,7 +783,9 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
     __syncthreads();
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
     if (slot >= n) return;
-    const PScan P = pscans[items[slot]];
+    const uint32_t me = items[slot];
+    if (me == PSCAN_NONE) return;  // (a batch of fewer than 64 files)
+    const PScan P = pscans[me];
     const uint32_t ii = P.image;
     const HImage *im = imgs + ii;
     const uint64_t img_fb = im->first_block;
@@ -759,6 +801,14 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
     BitR b;
     b.init(streams + im->stream_base + P.off, P.len);
     const uint32_t al = P.al;
+    {  // the scans that must have ended (all lanes of the wave take as many turns as the longest list needs)
+        uint32_t w = 0;
+        while (__any((int)(w < P.wait_count))) {
+            const uint32_t dep = w < P.wait_count ? waits[P.wait_first + w] : PSCAN_NONE;
+            if (!prog_wait(progress, dep, PSCAN_NONE, 0xFFFFFFFFu)) bad = 1;
+            w++;
+        }
+    }
     if (P.ss == 0) {
         // ---- DC scan: MCU order (one component: its own block grid, T.81 A.2.2)
         const uint32_t ns = P.ns;
@@ -792,8 +842,8 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                 p1 = i == 1 ? pv : p1;
                 p2 = i == 2 ? pv : p2;
                 coef[base] = (int16_t)(pv * (1 << al));
-            } else if (b.take(1)) {
-                atomicOr(reinterpret_cast<unsigned int *>(coef + base), 1u << al);  // coefficient 0 is the low half of the block's first dword
+            } else if (b.take(1)) {  // (kept beside the coefficients: the IDCT kernel puts the bit in)
+                dcbits[(size_t)sel3(i, P.dcb[0], P.dcb[1], P.dcb[2]) + (size_t)(my * Vc + v) * BWc + (mx * Hc + h)] = 1;
             }
             if (++h == Hc) {
                 h = 0;
@@ -823,18 +873,20 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
 #pragma unroll
             for (int j = 0; j < 16; j++) s_look8[(i0 + j) * 64 + lane] = (e[j] >> 8) <= 8 ? e[j] : (uint16_t)0;
         }
-        for (uint32_t i0 = 0; i0 < 256; i0 += 16) {
-            uint32_t w4[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) w4[j] = reinterpret_cast<const uint32_t *>(A->sym)[i0 / 4 + j];
-#pragma unroll
-            for (int j = 0; j < 16; j++) s_syms[(i0 + j) * 64 + lane] = (uint8_t)(w4[j >> 2] >> (8 * (j & 3)));
-        }
         LongCodes lc;  // the canonical arrays for codes of 9..16 bits stay in registers: with 64 lanes nearly every step has a lane that needs them
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             lc.maxc[j] = A->maxcode[9 + j];
             lc.dlt[j] = j ? A->delta[9 + j] - A->delta[8 + j] : A->delta[9];
+        }
+        lc.n_short = (uint32_t)(A->delta[9] + ((A->maxcode[8] >> 8) << 1)) & 255u;  // the first 9-bit code's symbol index = the number of shorter codes
+        lc.dlt[0] -= (int32_t)lc.n_short;
+        for (uint32_t j0 = 0; j0 < (uint32_t)PROG_LONG_SYMS; j0 += 4) {
+            uint8_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j] = A->sym[(lc.n_short + j0 + j) & 255u];
+#pragma unroll
+            for (int j = 0; j < 4; j++) s_syms[(j0 + j) * 64 + lane] = w[j];
         }
         if (P.ah == 0) {
             // first pass over the band: one symbol per step
@@ -844,8 +896,9 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
             const uint64_t max_it = (uint64_t)total * 65 + 8;
             for (uint64_t it = 0; bl < total && it < max_it; it++) {
                 RPH_PROG_STEP();
+                if (((uint32_t)it & (PROG_PUBLISH - 1)) == PROG_PUBLISH - 1) prog_publish(progress, me, bl);  // (the masks of the blocks before bl are out)
                 b.fill();
-                const uint32_t rs = b.symbol8(s_look8, lc, s_syms, lane);
+                const uint32_t rs = b.symbol8(s_look8, lc, s_syms, A->sym, lane);
                 if (rs > 255) {
                     bad = 1;
                     break;
@@ -916,7 +969,7 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                 for (int j = 0; j < PROG_GROUP; j++) {
                     pf[j] = 0;
                     if (f_bl < total) {
-                        pf[j] = my_masks[(size_t)(f_row_base + f_col - img_fb)];
+                        pf[j] = __hip_atomic_load(my_masks + (size_t)(f_row_base + f_col - img_fb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written in this launch)
                         f_bl++;
                         if (++f_col == MX) {
                             f_col = 0;
@@ -925,14 +978,20 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                     }
                 }
             };
-            fetch_group();
+            auto fetch_when_ready = [&]() {  // the scans this one follows must be past the blocks it is about to read the history of
+                const uint32_t need = f_bl + PROG_GROUP < total ? f_bl + PROG_GROUP : total;
+                if (!prog_wait(progress, P.chase[0], P.chase[1], f_bl < total ? need : 0u)) bad = 1;
+                fetch_group();
+            };
+            fetch_when_ready();
+            uint32_t steps = 0;
             unsigned long long nz_all = 0, nzb = 0, cb = 0, nz_new = 0;
             uint64_t base = 0;
             bool fresh = true;
             for (uint32_t g0 = 0; g0 < total && !bad; g0 += PROG_GROUP) {
 #pragma unroll
                 for (int j = 0; j < PROG_GROUP; j++) s_ring[j * 64 + lane] = pf[j];
-                fetch_group();
+                fetch_when_ready();
                 const uint32_t gend = g0 + PROG_GROUP < total ? g0 + PROG_GROUP : total;
                 while (bl < gend) {
                     if (fresh) {
@@ -946,12 +1005,13 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
                         fresh = false;
                     }
                     RPH_PROG_STEP();
+                    if ((++steps & (PROG_PUBLISH - 1)) == 0) prog_publish(progress, me, bl);  // (the masks of the blocks before bl have their placements)
                     b.fill();
                     uint32_t r = 0;
                     int value = 0;
                     bool place = false;  // a symbol of this block asks for a place; else only corrections are due
                     if (eobrun == 0) {
-                        const uint32_t rs = b.symbol8(s_look8, lc, s_syms, lane);
+                        const uint32_t rs = b.symbol8(s_look8, lc, s_syms, A->sym, lane);
                         if (rs > 255) {
                             bad = 1;
                             break;
@@ -1022,6 +1082,7 @@ __global__ void __launch_bounds__(64) jpeg_prog_kernel(const uint8_t *__restrict
         printf("scan ns=%u ss=%u se=%u ah=%u al=%u len=%u: %llu us, %u steps of this lane, %.2f us per step\n", P.ns, P.ss, P.se, P.ah, P.al, P.len, us, t_steps, (double)us / (t_steps ? t_steps : 1));
     }
 #endif
+    prog_publish(progress, me, 0xFFFFFFFFu);  // (whatever became of the scan: nobody waits for it any longer)
     if (bad) status[ii] = 1;  // (the results were zeroed before the launch; the scans of a file are different lanes)
 }
 
@@ -1336,13 +1397,13 @@ __global__ void __launch_bounds__(64) jpeg_seg_items_kernel(const SegFile *__res
 }  // namespace
 
 int rph_jpeg_launch_idct(int flavour, uint32_t max_blocks, uint32_t n_planes, hipStream_t stream, const int16_t *d_coef, const uint16_t *d_tables, const JPlane *d_planes,
-                         uint8_t *d_samples, const PRef *d_refs, const PCorr *d_corr)
+                         uint8_t *d_samples, const PRef *d_refs, const PCorr *d_corr, const uint8_t *d_dcbits)
 {
     const dim3 grid((max_blocks + 255) / 256, n_planes);
     if (flavour == RPH_JPEG_LIBJPEG)
-        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_LIBJPEG>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_samples, d_refs, d_corr);
+        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_LIBJPEG>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_samples, d_refs, d_corr, d_dcbits);
     else
-        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_ZUNE>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_samples, d_refs, d_corr);
+        hipLaunchKernelGGL(jpeg_idct_kernel<RPH_JPEG_ZUNE>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_samples, d_refs, d_corr, d_dcbits);
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }
@@ -1390,24 +1451,19 @@ int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HIm
     return RPH_OK;
 }
 
-int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const PScan *d_pscans, const uint32_t *d_items,
-                         const uint32_t *level_count, uint32_t n_levels, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, unsigned long long *d_masks,
-                         PCorr *d_corr, size_t n_corr, uint8_t *d_status)
+int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const PScan *d_pscans, uint32_t n_pscans, const uint32_t *d_items,
+                         uint32_t n_items, const uint32_t *d_waits, const rphj::DeviceLut *d_luts, uint32_t n_luts, int16_t *d_coef, unsigned long long *d_masks,
+                         uint32_t *d_progress, PCorr *d_corr, size_t n_corr, uint8_t *d_dcbits, size_t n_dcbits, uint8_t *d_status)
 {
-    if (n_levels == 0) return RPH_OK;
+    if (n_items == 0) return RPH_OK;
+    (void)n_pscans;  // (d_progress: one word per scan, zeroed by the caller with the masks)
     if (n_corr) RPH_HIP_CHECK(hipMemsetAsync(d_corr, 0, n_corr * sizeof(PCorr), stream));
-    uint32_t first = 0;
-    for (uint32_t l = 0; l < n_levels; l++) {  // the scans of a level only read what earlier levels wrote: the launches are the dependencies
-        const uint32_t n = level_count[l];
-        if (n == 0) continue;
-        const dim3 grid((n + 63) / 64);
-        if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
-            hipLaunchKernelGGL(jpeg_prog_kernel<HUFF_LDS_TABLES>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_items + first, n, d_luts, n_luts, d_coef, d_masks, d_corr,
-                               d_status);
-        else
-            hipLaunchKernelGGL(jpeg_prog_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_items + first, n, d_luts, n_luts, d_coef, d_masks, d_corr, d_status);
-        first += n;
-    }
+    if (n_dcbits) RPH_HIP_CHECK(hipMemsetAsync(d_dcbits, 0, n_dcbits, stream));
+    const dim3 grid((n_items + 63) / 64);
+    // (the DC tables stay in memory whatever their number: 40 KB of LDS per wave are four waves per CU, and the launch needs the slots --
+    // the scans of a file that follow one another must be resident together)
+    hipLaunchKernelGGL(jpeg_prog_kernel<0>, grid, dim3(64), 0, stream, d_streams, d_images, d_pscans, d_items, n_items, d_waits, d_luts, n_luts, d_coef, d_masks, d_progress, d_corr,
+                       d_dcbits, d_status);
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
 }

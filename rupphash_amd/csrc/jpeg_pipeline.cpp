@@ -84,6 +84,8 @@ struct Slot {
     size_t pmask_cap = 0;
     PCorr *d_pcorr = nullptr;               // and the records of their AC refinement scans (jpeg_device.h)
     size_t pcorr_cap = 0;
+    uint8_t *d_pdc = nullptr;               // and the bits of their DC refinement scans, one byte per block
+    size_t pdc_cap = 0;
     void release()
     {
         if (stream) (void)hipStreamSynchronize(stream);
@@ -95,6 +97,7 @@ struct Slot {
         if (d_segwork) (void)hipFree(d_segwork);
         if (d_pmask) (void)hipFree(d_pmask);
         if (d_pcorr) (void)hipFree(d_pcorr);
+        if (d_pdc) (void)hipFree(d_pdc);
         if (stream) (void)hipStreamDestroy(stream);
         if (done) (void)hipEventDestroy(done);
         *this = Slot();
@@ -358,6 +361,7 @@ struct ChunkDesc {
     uint32_t n_planes = 0, n_images = 0;
     const PRef *d_refs = nullptr;   // device entropy, progressive files: the AC refinement scans of their planes and the records of
     const PCorr *d_corr = nullptr;  // their corrections (the IDCT kernel applies them)
+    const uint8_t *d_dcbits = nullptr;
 };
 
 // Sub-batch boundaries are where the offsets of planes and pixels restart from 0: `sub_of[r]` = first chunk position of r's sub-batch.
@@ -454,7 +458,7 @@ int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, Jobs &jobs, 
     const JPlane *dp = reinterpret_cast<const JPlane *>(S.meta.d + D.off_planes) + p0;
     const JImage *di = reinterpret_cast<const JImage *>(S.meta.d + D.off_images) + i0;
     const uint16_t *dq = reinterpret_cast<const uint16_t *>(S.meta.d + D.off_tables);
-    RPH_TRY(rph_jpeg_launch_idct(flavour, max_blocks, p1 - p0, s, d_coef, dq, dp, P.d_planes[b], D.d_refs, D.d_corr));
+    RPH_TRY(rph_jpeg_launch_idct(flavour, max_blocks, p1 - p0, s, d_coef, dq, dp, P.d_planes[b], D.d_refs, D.d_corr, D.d_dcbits));
     RPH_TRY(rph_jpeg_launch_color(flavour, max_groups, i1 - i0, s, P.d_planes[b], di, P.d_out[b]));
     if (!out.want_hash) return RPH_OK;
     // hash runs of equal geometry where the pixels lie (generate_pdq_features, scanner.rs:1410)
@@ -790,7 +794,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         std::vector<SegFile> seg_files;
         std::vector<PScan> pscans;            // the scans of the chunk's progressive files
         std::vector<uint32_t> prog_order;     // the progressive files (indices into the chunk)
-        std::vector<uint32_t> pscan_level;    // per scan: its depth in the order "needs an earlier scan of the same coefficients" (a launch per depth)
+        std::vector<uint32_t> pwaits;         // scans (indices into pscans) that must have ended before a scan begins (PScan::wait_first / wait_count)
         std::vector<PRef> prefs;              // their AC refinement scans, grouped by plane (file order within a plane)
         struct PlaneRefs {
             uint32_t r, first[3], count[3];
@@ -798,6 +802,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         std::vector<PlaneRefs> plane_refs;
         uint64_t prog_blocks = 0;             // their blocks: one mask word each
         uint64_t prog_corr = 0;               // records of their AC refinement scans
+        uint64_t prog_dcb = 0;                // bytes of their DC refinement scans
         uint32_t n_segs = 0;
         bool all_one_scan = true;  // every sequential file of the chunk has one scan: its MCUs cover all blocks of its components
         items.reserve(m);
@@ -819,27 +824,54 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                     ps.ac = sp.ac[0];
                     ps.image = r;
                     ps.corr_first = 0;
+                    ps.dcb[0] = ps.dcb[1] = ps.dcb[2] = 0;
+                    if (sp.ss == 0 && sp.ah > 0) {
+                        for (int c = 0; c < sp.ns && c < 3; c++) {
+                            const rphj::Comp &kc = j.frame.comp[sp.ci[c]];
+                            ps.dcb[c] = (uint32_t)prog_dcb;
+                            prog_dcb += (uint64_t)kc.blocks_w * kc.blocks_h;
+                        }
+                    }
                     if (sp.ss > 0 && sp.ah > 0) {
                         const rphj::Comp &kc = j.frame.comp[sp.ci[0]];
                         ps.corr_first = (uint32_t)prog_corr;
                         prog_corr += (uint64_t)kc.real_bw * kc.real_bh;
                     }
-                    // depth: one more than the deepest earlier scan of this file that shares a component and a coefficient with this one
-                    uint32_t level = 0;
+                    // The scans this one must come after: the earlier scans of the file that share a component and a coefficient with it.
+                    // An AC scan follows up to two of them (the longest) block by block (PScan::chase); the others must have ended.
+                    ps.chase[0] = ps.chase[1] = PSCAN_NONE;
+                    ps.wait_first = (uint32_t)pwaits.size();
                     auto comps = [](const PScan &x) { uint32_t m = 0; for (uint32_t c = 0; c < x.ns && c < 3; c++) m |= 1u << x.ci[c]; return m; };
+                    std::vector<uint32_t> deps;
                     for (size_t q = p0; q < pscans.size(); q++) {
                         const PScan &e = pscans[q];
-                        if ((comps(e) & comps(ps)) && e.ss <= ps.se && ps.ss <= e.se) level = std::max(level, pscan_level[q] + 1);
+                        if ((comps(e) & comps(ps)) && e.ss <= ps.se && ps.ss <= e.se) deps.push_back((uint32_t)q);
                     }
+                    if (ps.ss > 0) {  // (AC scans of one component walk the same raster of blocks)
+                        std::stable_sort(deps.begin(), deps.end(), [&](uint32_t a, uint32_t b) { return pscans[a].len > pscans[b].len; });
+                        for (size_t d = 0; d < deps.size(); d++) {
+                            if (d < 2)
+                                ps.chase[d] = deps[d];
+                            else
+                                pwaits.push_back(deps[d]);
+                        }
+                    } else if (ps.ah == 0) {
+                        pwaits.insert(pwaits.end(), deps.begin(), deps.end());
+                    }  // (a DC refinement scan writes its bits beside the coefficients and reads nothing: it waits for nobody)
+                    ps.wait_count = (uint32_t)pwaits.size() - ps.wait_first;
                     pscans.push_back(ps);
-                    pscan_level.push_back(level);
                 }
                 PlaneRefs pr;
                 pr.r = r;
                 for (uint32_t c = 0; c < 3; c++) {
                     pr.first[c] = (uint32_t)prefs.size();
-                    for (size_t q = p0; q < pscans.size(); q++)
-                        if (pscans[q].ss > 0 && pscans[q].ah > 0 && pscans[q].ci[0] == c) prefs.push_back(PRef{pscans[q].corr_first, pscans[q].al});
+                    for (size_t q = p0; q < pscans.size(); q++) {
+                        const PScan &x = pscans[q];
+                        if (x.ss > 0 && x.ah > 0 && x.ci[0] == c) prefs.push_back(PRef{x.corr_first, x.al});
+                        if (x.ss == 0 && x.ah > 0)
+                            for (uint32_t k = 0; k < x.ns && k < 3; k++)
+                                if (x.ci[k] == c) prefs.push_back(PRef{x.dcb[k], x.al | PREF_DC});
+                    }
                     pr.count[c] = (uint32_t)prefs.size() - pr.first[c];
                 }
                 plane_refs.push_back(pr);
@@ -880,20 +912,57 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 item_len.push_back(end > off ? end - off : 0);
             }
         }
-        // the lanes of a launch: the scans of one depth, scans of one kind together (the lanes of a wave run the same loop), longest first
-        std::vector<uint32_t> pitems(pscans.size()), level_count;
-        for (uint32_t t = 0; t < pitems.size(); t++) pitems[t] = t;
+        // The lanes of the launch: 64 files of one scan script make a batch, and wave k of a batch walks the k-th scan of each of them -- one
+        // kind of scan per wave, and a scan's producers in earlier workgroups of the same launch, which start first (jpeg_kernels.hip).
+        std::vector<uint32_t> pitems;
         {
-            auto kind = [&](uint32_t t) { return (pscans[t].ss ? 2u : 0u) + (pscans[t].ah ? 1u : 0u); };
-            std::stable_sort(pitems.begin(), pitems.end(), [&](uint32_t a, uint32_t b) {
-                if (pscan_level[a] != pscan_level[b]) return pscan_level[a] < pscan_level[b];
-                if (kind(a) != kind(b)) return kind(a) > kind(b);  // (refinements of AC bands are the slowest per byte: first)
-                return pscans[a].len > pscans[b].len;
-            });
-            for (uint32_t t : pitems) {
-                if (pscan_level[t] >= level_count.size()) level_count.resize(pscan_level[t] + 1, 0);
-                level_count[pscan_level[t]]++;
+            auto signature = [&](uint32_t r) {
+                uint64_t h = 1469598103934665603ull;
+                for (uint32_t q = 0; q < himgs[r].pscan_count; q++) {
+                    const PScan &x = pscans[himgs[r].pscan_first + q];
+                    const uint32_t f[6] = {x.ns, x.ss, x.se, x.ah, x.al, x.ci[0] | (x.ci[1] << 8) | (x.ci[2] << 16)};
+                    for (uint32_t v : f) h = (h ^ v) * 1099511628211ull;
+                }
+                return h;
+            };
+            std::vector<std::pair<uint64_t, uint32_t>> sig(prog_order.size());  // (script, file), files of a script in the chunk's order: longest first
+            for (size_t t = 0; t < prog_order.size(); t++) sig[t] = {signature(prog_order[t]), prog_order[t]};
+            std::stable_sort(sig.begin(), sig.end(), [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a.first < b.first; });
+            // A wave = (batch, k-th scan).  Waves go into the grid by how much work still hangs on them -- their own (bytes x the rate of their
+            // kind of scan) plus the longest chain of scans behind them -- so the scans on a file's critical path (libjpeg's script: luma 6-63,
+            // then its two refinements) start at once for every batch and the short scans fill the slots that are left; a producer always
+            // ranks above its consumers, i.e. comes first in the grid.
+            struct Wave {
+                double rank;
+                uint32_t batch, first, count, k;  // files sig[first .. first + count), their k-th scans
+            };
+            std::vector<Wave> waves;
+            uint32_t n_batches = 0;
+            for (size_t t0 = 0; t0 < sig.size();) {
+                size_t t1 = t0;
+                while (t1 < sig.size() && t1 - t0 < 64 && sig[t1].first == sig[t0].first) t1++;
+                const HImage &h0 = himgs[sig[t0].second];  // (the batch's longest file stands for all of them)
+                const uint32_t n_scans = h0.pscan_count;
+                std::vector<double> rank(n_scans, 0.0);
+                for (uint32_t q = n_scans; q-- > 0;) {
+                    const PScan &x = pscans[h0.pscan_first + q];
+                    double behind = 0.0;
+                    for (uint32_t c = q + 1; c < n_scans; c++) {  // scans that wait for q or follow it
+                        const PScan &y = pscans[h0.pscan_first + c];
+                        bool dep = y.chase[0] == h0.pscan_first + q || y.chase[1] == h0.pscan_first + q;
+                        for (uint32_t w = 0; w < y.wait_count && !dep; w++) dep = pwaits[y.wait_first + w] == h0.pscan_first + q;
+                        if (dep) behind = std::max(behind, rank[c]);
+                    }
+                    rank[q] = (double)x.len * (x.ss && x.ah ? 1.05 : 0.55) + 1.0 + behind;
+                }
+                for (uint32_t q = 0; q < n_scans; q++) waves.push_back(Wave{rank[q], n_batches, (uint32_t)t0, (uint32_t)(t1 - t0), q});
+                n_batches++;
+                t0 = t1;
             }
+            std::stable_sort(waves.begin(), waves.end(), [](const Wave &a, const Wave &b) { return a.rank > b.rank; });
+            pitems.reserve(waves.size() * 64);
+            for (const Wave &w : waves)
+                for (uint32_t l = 0; l < 64; l++) pitems.push_back(l < w.count ? himgs[sig[w.first + l].second].pscan_first + w.k : PSCAN_NONE);
         }
         std::vector<uint32_t> order(items.size());
         for (uint32_t t = 0; t < order.size(); t++) order[t] = t;
@@ -912,7 +981,8 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         const size_t off_himg = align_up(recon_bytes, 16), off_order = off_himg + m * sizeof(HImage), off_luts = align_up(off_order + order.size() * 4, 16),
                      off_segf = align_up(off_luts + luts.size() * sizeof(rphj::DeviceLut), 16), off_pscan = align_up(off_segf + seg_files.size() * sizeof(SegFile), 16),
                      off_porder = off_pscan + pscans.size() * sizeof(PScan), off_pitems = off_porder + prog_order.size() * 4,
-                     off_prefs = align_up(off_pitems + pitems.size() * 4, 16), off_items = align_up(off_prefs + prefs.size() * sizeof(PRef), 16),
+                     off_prefs = align_up(off_pitems + pitems.size() * 4, 16), off_pwaits = align_up(off_prefs + prefs.size() * sizeof(PRef), 16),
+                     off_items = align_up(off_pwaits + pwaits.size() * 4, 16),
                      upload_bytes = off_items + items.size() * sizeof(HItem), meta_bytes = off_items + (size_t)n_items * sizeof(HItem);
         RPH_TRY(S.meta.reserve(meta_bytes));
         const size_t segwork = align_up((size_t)n_segs * sizeof(SegState), 16) + rph_jpeg_segment_work_bytes(n_segs);
@@ -923,18 +993,26 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             S.segwork_cap = segwork + segwork / 4;
         }
         if (prog_blocks >= ((uint64_t)1 << 32)) return RPH_ERR_CAPACITY;  // (a chunk's coefficients are capped far below: 2^32 blocks are 512 GB)
-        if (prog_corr >= ((uint64_t)1 << 32)) return RPH_ERR_CAPACITY;
+        if (prog_corr >= ((uint64_t)1 << 32) || prog_dcb >= ((uint64_t)1 << 32)) return RPH_ERR_CAPACITY;
+        if (prog_dcb && S.pdc_cap < prog_dcb) {
+            if (S.d_pdc) (void)hipFree(S.d_pdc);
+            S.d_pdc = nullptr, S.pdc_cap = 0;
+            RPH_HIP_CHECK(hipMalloc((void **)&S.d_pdc, prog_dcb + prog_dcb / 4 + 64));
+            S.pdc_cap = prog_dcb + prog_dcb / 4 + 64;
+        }
         if (prog_corr && S.pcorr_cap < prog_corr * sizeof(PCorr)) {
             if (S.d_pcorr) (void)hipFree(S.d_pcorr);
             S.d_pcorr = nullptr, S.pcorr_cap = 0;
             RPH_HIP_CHECK(hipMalloc((void **)&S.d_pcorr, prog_corr * sizeof(PCorr) + prog_corr * 4));
             S.pcorr_cap = prog_corr * sizeof(PCorr) + prog_corr * 4;
         }
-        if (prog_blocks && S.pmask_cap < prog_blocks * 8) {
+        // (one mask word per block, and behind them one progress word per scan)
+        const size_t pmask_need = prog_blocks * 8 + align_up(pscans.size() * 4, 16);
+        if (prog_blocks && S.pmask_cap < pmask_need) {
             if (S.d_pmask) (void)hipFree(S.d_pmask);
             S.d_pmask = nullptr, S.pmask_cap = 0;
-            RPH_HIP_CHECK(hipMalloc((void **)&S.d_pmask, prog_blocks * 8 + prog_blocks * 2));
-            S.pmask_cap = prog_blocks * 8 + prog_blocks * 2;
+            RPH_HIP_CHECK(hipMalloc((void **)&S.d_pmask, pmask_need + pmask_need / 4));
+            S.pmask_cap = pmask_need + pmask_need / 4;
         }
         ChunkDesc D;
         std::vector<size_t> subs;
@@ -948,6 +1026,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             memcpy(S.meta.h + off_pscan, pscans.data(), pscans.size() * sizeof(PScan));
             memcpy(S.meta.h + off_porder, prog_order.data(), prog_order.size() * 4);
             memcpy(S.meta.h + off_pitems, pitems.data(), pitems.size() * 4);
+            if (!pwaits.empty()) memcpy(S.meta.h + off_pwaits, pwaits.data(), pwaits.size() * 4);
             if (!prefs.empty()) {
                 memcpy(S.meta.h + off_prefs, prefs.data(), prefs.size() * sizeof(PRef));
                 JPlane *hp = reinterpret_cast<JPlane *>(S.meta.h + D.off_planes);
@@ -958,6 +1037,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 }
                 D.d_refs = reinterpret_cast<const PRef *>(S.meta.d + off_prefs);
                 D.d_corr = S.d_pcorr;
+                D.d_dcbits = S.d_pdc;
             }
         }
         // ---- device: streams up, zeroed coefficients, the walk, then reconstruction + hashing sub-batch by sub-batch
@@ -993,11 +1073,11 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 RPH_TRY(rph_jpeg_launch_walk(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const HItem *>(S.meta.d + off_items),
                                              reinterpret_cast<const uint32_t *>(S.meta.d + off_order), n_ordered, n_items,
                                              reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, R.status));
-            if (prog_blocks) RPH_HIP_CHECK(hipMemsetAsync(S.d_pmask, 0, prog_blocks * 8, s));
+            if (prog_blocks) RPH_HIP_CHECK(hipMemsetAsync(S.d_pmask, 0, prog_blocks * 8 + align_up(pscans.size() * 4, 16), s));
             RPH_TRY(rph_jpeg_launch_prog(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const PScan *>(S.meta.d + off_pscan),
-                                         reinterpret_cast<const uint32_t *>(S.meta.d + off_pitems), level_count.data(), (uint32_t)level_count.size(),
-                                         reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), d_coef, S.d_pmask, S.d_pcorr, (size_t)prog_corr,
-                                         R.status));
+                                         (uint32_t)pscans.size(), reinterpret_cast<const uint32_t *>(S.meta.d + off_pitems), (uint32_t)pitems.size(),
+                                         reinterpret_cast<const uint32_t *>(S.meta.d + off_pwaits), reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts),
+                                         (uint32_t)luts.size(), d_coef, S.d_pmask, reinterpret_cast<uint32_t *>(S.d_pmask + prog_blocks), S.d_pcorr, (size_t)prog_corr, S.d_pdc, (size_t)prog_dcb, R.status));
             lap(t_walk);
             for (size_t q = 0; q < subs.size(); q++) {
                 const size_t r0 = subs[q], r1 = q + 1 < subs.size() ? subs[q + 1] : m;
