@@ -611,15 +611,15 @@ __global__ void __launch_bounds__(STAGE_WAVES > 0 ? STAGE_WAVES * 64 : 64) jpeg_
 // Progressive files (T.81 G.1.2), one SCAN per lane, each over its component's whole block grid -- first DC (difference coding,
 // value << Al), DC refinement (one bit per block), first AC of a band (runs, end-of-band runs over blocks), AC refinement (a correction
 // bit for every coefficient that is already nonzero, new +-1 values in between).  A scan needs the scans before it that touch the same
-// coefficients of the same component, and no others: the host sorts the scans of all files by their depth in that order and every depth
-// is one launch (the usual ten-scan script has three: five first scans side by side, four refinements, the last luma refinement).
-// Nothing here ever waits for a coefficient to come back from memory.  First scans only write.  Refinement needs to know WHICH
-// coefficients of a block are nonzero, not their values: one 64-bit mask per block (zigzag position = bit) is kept beside the
-// coefficients -- first AC scans and the placements of refinement scans OR into it with fire-and-forget atomics, a refinement scan
-// reads the words of the next sixteen blocks while it walks the current sixteen out of LDS.  The corrections of an AC refinement scan
-// are collected, not applied: per block the history the scan saw and the correction bits, which jpeg_prog_apply_kernel adds to the
-// coefficients afterwards with a lane per coefficient.  DC refinement is an atomic OR.  Every access stays inside the file's own blocks
-// and records whatever a damaged stream says.
+// coefficients of the same component, and no others, and it needs them block by block: all scans of a chunk are ONE launch in which a
+// scan follows its predecessors a few blocks behind (progress words, jpeg_device.h; the host orders the waves so that a producer
+// starts before its consumers).  Nothing here ever waits for a coefficient to come back from memory, and no coefficient is written
+// twice.  First scans only write.  Refinement needs to know WHICH coefficients of a block are nonzero, not their values: one 64-bit
+// mask per block (zigzag position = bit) is kept beside the coefficients -- first AC scans and the placements of refinement scans OR
+// into it with device-scope atomics, a refinement scan reads the words of the next eight blocks (device-scope atomic loads) while it
+// walks the current eight out of LDS.  The corrections of an AC refinement scan are collected, not applied: per block the history the
+// scan saw and the correction bits; a DC refinement scan leaves its bit per block; the IDCT kernel adds both to the coefficients with a
+// lane per block.  Every access stays inside the file's own blocks and records whatever a damaged stream says.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct LongCodes {  // of one Huffman table: exclusive upper bounds of the codes of 9..16 bits in a 16-bit window; symbol index = (window >> (16 - length)) + delta[length],
     int32_t maxc[8], dlt[8];  // dlt[0] = delta[9] - n_short, dlt[j] = delta[9 + j] - delta[8 + j]: the bounds grow with the length, so the reached ones add up to delta[length] - n_short
