@@ -289,6 +289,29 @@ def test_progressive_files_walk_on_the_device(eng, oracle):
     # DCT coefficient anywhere in such a file shows)
 
 
+def test_progressive_scans_follow_their_producers_across_many_batches(eng, oracle):
+    """all scans of a chunk are one launch in which a scan follows the scans it depends on block by block (progress words): several hundred
+    files of libjpeg's script and of a script whose refinements come before other bands' first scans, in sizes from one block to 400 x 300
+    -- full batches of 64, part batches, scans of very different lengths side by side -- must come out like the host decoder's, twice
+    (the second call reuses every buffer, progress words included)"""
+    files = []
+    for k in range(150):
+        w, h = [(400, 300), (64, 48), (8, 8), (233, 177), (120, 200)][k % 5]
+        files.append(ju.pillow_jpeg(ju.make_image(w + k % 7, h + k % 3, "RGB", seed=900 + k), quality=[60, 85, 95][k % 3], subsampling=[2, 1, 0][k % 3], progressive=True))
+    for k in range(70):
+        files.append(ju.encode_progressive(np.asarray(ju.make_image(96 + k, 80, "RGB", seed=1300 + k)), ju.SCRIPT_REFINE_BEFORE_OTHER_BANDS, quality_scale=1.0))
+    eng.jpeg_set_entropy(0)
+    host = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    eng.jpeg_set_entropy(1)
+    try:
+        for rep in range(2):
+            dev = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+            assert not dev["status"].any() and np.array_equal(dev["valid"], host["valid"])
+            assert np.array_equal(dev["hash"], host["hash"]) and np.array_equal(dev["coeffs"].view(np.uint32), host["coeffs"].view(np.uint32))
+    finally:
+        eng.jpeg_set_entropy(2)
+
+
 def test_progressive_scan_scripts_on_the_device(eng, oracle):
     """the device walk of progressive files on what Pillow cannot write (tests/jpeg_util.encode_progressive): bands refined in another order
     than they were first coded (the masks a refinement scan reads were last changed by atomics of an earlier scan), successive approximation
