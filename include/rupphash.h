@@ -385,7 +385,7 @@ int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int fla
 #define RPH_JPEG_ENTROPY_AUTO 2
 #define RPH_JPEG_ENTROPY_DEVICE_SEQUENTIAL 3
 int rph_jpeg_set_entropy(rph_ctx *ctx, int where);
-/* Tuning of the device walk for streams WITHOUT restart markers: from min_stream_bytes of entropy-coded data (default 65536) a
+/* Tuning of the device walk for streams WITHOUT restart markers: from min_stream_bytes of entropy-coded data (default 8192) a
  * stream is cut into segments of segment_bytes (default 1024; a multiple of 4 in 64 .. 65536; 0 = never) that find their
  * entry points on the device (Huffman streams re-synchronise; the chain of entries is verified, a file that does not verify is
  * walked by one lane) and are then walked side by side -- unless, for a chunk of the call, one lane per file is estimated to be

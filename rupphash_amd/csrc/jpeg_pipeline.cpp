@@ -613,6 +613,13 @@ int run_host_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, const std::vector<ui
 }
 
 // ---- device entropy decoding: the sequential files idx[...]; files the device walk does not take come back in `leftover` for the host
+// entropy bytes per second the segment passes (synchronisation + walk) move when the device is theirs: 2 GB in 14 + 18 ms
+inline double seg_rate()
+{
+    static const double r = getenv("RPH_JPEG_SEG_RATE") ? atof(getenv("RPH_JPEG_SEG_RATE")) * 1e9 : 60e9;
+    return r;
+}
+
 int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32_t> idx, int flavour, unsigned threads, const Outputs &out,
                        std::vector<uint32_t> &leftover)
 {
@@ -654,7 +661,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     }
     bool by_segments = false;
     if (plain_files) {  // will a quarter of them be walked as segments (the chunk loop decides the same way, per chunk)?
-        const double t_whole = 0.65e-6 * (double)longest_plain * std::max(1.0, (double)plain_files / 4 / 65536.0), t_seg = (double)plain_bytes / 4 / 31e9;
+        const double t_whole = 0.65e-6 * (double)longest_plain * std::max(1.0, (double)plain_files / 4 / 65536.0), t_seg = (double)plain_bytes / 4 / seg_rate();
         by_segments = t_seg < 0.7 * t_whole;
         max_len = std::max(max_len, by_segments ? (size_t)ctx->jpeg_seg_bytes : longest_plain);
     }
@@ -786,7 +793,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         // 103).  Whole-file walks also leave most of the device to the other lane's chunk, so segments must win clearly.
         bool use_segments = ctx->jpeg_seg_bytes != 0;
         if (use_segments && ctx->jpeg_seg_min_bytes > 0) {
-            const double t_whole = 0.65e-6 * (double)jobs[idx[first]].len * std::max(1.0, (double)m / 65536.0), t_seg = (double)file_bytes / 31e9;
+            const double t_whole = 0.65e-6 * (double)jobs[idx[first]].len * std::max(1.0, (double)m / 65536.0), t_seg = (double)file_bytes / seg_rate();
             use_segments = t_seg < 0.7 * t_whole;
         }
         std::vector<HItem> items;

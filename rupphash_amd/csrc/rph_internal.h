@@ -62,7 +62,7 @@ struct rph_ctx {
     int jpeg_progressive_on_device = 1;  // 0: progressive files stay with the host threads (rph_jpeg_set_entropy(ctx, 3))
     // device walk of streams without restart markers: from jpeg_seg_min_bytes of entropy data a stream is cut into segments of
     // jpeg_seg_bytes that synchronise on the device and are walked side by side (0 = never)
-    uint32_t jpeg_seg_min_bytes = 65536, jpeg_seg_bytes = 1024;
+    uint32_t jpeg_seg_min_bytes = 8192, jpeg_seg_bytes = 1024;
     // rph_jpeg_pdq_hash_one: callers that arrive while a batch is on its way wait here and leave together as the next batch
     std::mutex jpeg_qmu;
     std::condition_variable jpeg_qcv;

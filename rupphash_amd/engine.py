@@ -134,7 +134,7 @@ class Engine:
                                            C.cast(C.byref(valid), C.c_void_p)), "rph_jpeg_pdq_hash_one")
         return (hash32, q.value, coeffs) if valid.value else None
 
-    def jpeg_set_segments(self, min_stream_bytes=65536, segment_bytes=1024):
+    def jpeg_set_segments(self, min_stream_bytes=8192, segment_bytes=1024):
         """device walk of streams without restart markers: cut into segments from min_stream_bytes of entropy data (segment_bytes = 0: never)"""
         check(self.L.rph_jpeg_set_segments(self.ctx, int(min_stream_bytes), int(segment_bytes)), "rph_jpeg_set_segments")
 

@@ -244,13 +244,37 @@ def test_streams_without_markers_cut_into_segments(eng, oracle, seg_bytes):
     eng.jpeg_set_entropy(1)
     eng.jpeg_set_segments(0, seg_bytes)
     dev = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
-    eng.jpeg_set_segments(65536, 1024)
+    eng.jpeg_set_segments()  # (the defaults)
     eng.jpeg_set_entropy(2)
     assert dev["valid"].all() and not dev["status"].any()
     assert np.array_equal(dev["hash"], host["hash"]) and np.array_equal(dev["coeffs"].view(np.uint32), host["coeffs"].view(np.uint32))
     for k in (0, 4, 8, 9):
         ok, h, _, _ = _oracle_hash(oracle, oracle.jpeg_decode(files[k], 0))
         assert ok and np.array_equal(dev["hash"][k], h)
+
+
+def test_a_launch_of_many_segment_lanes_builds_its_blocks_in_lds(eng, oracle):
+    """from 262 144 lanes per launch the walk stages every block in LDS and writes it out whole, and a chunk whose files all have one scan
+    is not zeroed first: 832 photo-sized files without restart markers (about 300 000 segments of 1 KB), twice -- the second call finds
+    the first call's coefficients in the buffer -- with a smaller, different set in between; results must be the host decoder's"""
+    from PIL import Image
+
+    im = Image.open(os.path.join(GOLDEN, "bench.jpg"))
+    im.load()
+    crops = [ju.pillow_jpeg(im.crop((k % 8, k // 8, k % 8 + 1265, k // 8 + 850)), quality=90, subsampling=2) for k in range(32)]
+    files = [crops[k % 32] for k in range(832)]
+    other = [ju.pillow_jpeg(ju.make_image(1100 + 8 * k, 700, "RGB", seed=4000 + k), quality=85, subsampling=[2, 1, 0][k % 3]) for k in range(6)] * 60
+    eng.jpeg_set_entropy(0)
+    host = eng.jpeg_pdq_hash_batch(files, threads=16)
+    host_other = eng.jpeg_pdq_hash_batch(other, threads=16)
+    eng.jpeg_set_entropy(1)
+    try:
+        for batch, want in ((files, host), (other, host_other), (files, host)):
+            dev = eng.jpeg_pdq_hash_batch(batch, threads=16)
+            assert dev["valid"].all() and not dev["status"].any()
+            assert np.array_equal(dev["hash"], want["hash"])
+    finally:
+        eng.jpeg_set_entropy(2)
 
 
 def test_progressive_files_walk_on_the_device(eng, oracle):

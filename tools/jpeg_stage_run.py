@@ -42,6 +42,8 @@ else:
         base = list(pool.map(lambda k: enc(np.asarray(im.crop((k % 16, k // 16, k % 16 + 1265, k // 16 + 850))), quality=90, subsampling=2, progressive=(kind == "prog")), range(distinct)))
 files = eng.jpeg_file_list([base[k % distinct] for k in range(n)])
 eng.jpeg_set_entropy(1)
+if os.environ.get("RPH_SEG_MIN"):  # experiments: segments from that many entropy bytes on, of RPH_SEG_BYTES each
+    eng.jpeg_set_segments(int(os.environ["RPH_SEG_MIN"]), int(os.environ.get("RPH_SEG_BYTES", "1024")))
 eng.jpeg_pdq_hash_batch(files, threads=threads)  # buffers
 t0 = time.perf_counter()
 for _ in range(calls):
