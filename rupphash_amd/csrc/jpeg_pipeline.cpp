@@ -178,7 +178,7 @@ constexpr size_t MAX_IMAGE_COEF_BYTES = (size_t)3 << 30;  // one image beyond th
 static inline bool frame_is_plausible(const rphj::Frame &f, size_t file_len) { return (size_t)f.total_blocks <= 8 * file_len + 64; }
 constexpr uint32_t CHUNK_MAX_IMAGES = 4096;               // host entropy
 constexpr size_t SUB_MAX_IMAGES = 16384;                  // images per reconstruction sub-batch (grid.y of the kernels: 3 planes each)
-constexpr uint32_t DEVICE_ENTROPY_MIN_FILES = 2048;       // automatic mode: below this many lanes (files, or restart intervals) the host decodes (latency)
+constexpr uint32_t DEVICE_ENTROPY_MIN_FILES = 512;        // automatic mode: below this many lanes (files, or restart intervals) the host decodes (latency)
 
 // Huffman tables of a chunk, one per distinct content (most files of a collection share the four Annex K tables)
 struct TableStore {
@@ -1146,7 +1146,7 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
     //    segments, whose passes cost ~10 ms of launches before they scale: counted as a lane per 8 KB, so that ~50 photos qualify (16 host
     //    threads decode 130 MB/s each);
     //  * progressive files, one lane each whatever their size, when the host threads (~41 MB/s each) would need longer for all of them
-    //    than a lane needs for the longest (~0.95 us per byte).
+    //    than the device needs for the longest (~0.6 us per byte of the file: its scans follow one another block by block).
     std::vector<uint32_t> host_idx, dev_idx;
     const bool may_device = ctx->jpeg_entropy != 0 && out.want_hash && !prepared;
     uint64_t lanes = 0, prog_bytes = 0, prog_longest = 0;
@@ -1167,7 +1167,7 @@ int run_batch(rph_ctx *ctx, const uint8_t *const *data, const size_t *len, uint3
     }
     const bool seq_on_device = may_device && (ctx->jpeg_entropy == 1 || lanes >= DEVICE_ENTROPY_MIN_FILES);
     const bool prog_on_device = may_device && ctx->jpeg_progressive_on_device &&
-                                (ctx->jpeg_entropy == 1 || (double)prog_bytes / ((double)threads * 41e6) > 0.95e-6 * (double)prog_longest);
+                                (ctx->jpeg_entropy == 1 || (double)prog_bytes / ((double)threads * 41e6) > 0.6e-6 * (double)prog_longest);
     for (uint32_t i = 0; i < n; i++) {
         const Job &j = jobs[i];
         if (j.status == RPH_OK && (j.frame.progressive ? prog_on_device : seq_on_device))
