@@ -254,7 +254,7 @@ def test_streams_without_markers_cut_into_segments(eng, oracle, seg_bytes):
 
 
 def test_a_launch_of_many_segment_lanes_builds_its_blocks_in_lds(eng, oracle):
-    """from 262 144 lanes per launch the walk stages every block in LDS and writes it out whole, and a chunk whose files all have one scan
+    """from 131 072 lanes per launch the walk stages every block in LDS and writes it out whole, and a chunk whose files all have one scan
     is not zeroed first: 832 photo-sized files without restart markers (about 300 000 segments of 1 KB), twice -- the second call finds
     the first call's coefficients in the buffer -- with a smaller, different set in between; results must be the host decoder's"""
     from PIL import Image
