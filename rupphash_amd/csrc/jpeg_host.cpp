@@ -700,6 +700,8 @@ int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, 
     uint8_t *o = out, *o_end = out + cap;
     size_t pos = 2;
     uint32_t done_mask = 0;
+    int8_t coef_bits[4][64];  // progressive files: the Al each coefficient of each component was last coded with (-1: not yet)
+    memset(coef_bits, -1, sizeof coef_bits);
     for (;;) {
         while (pos < len && data[pos] != 0xFF) pos++;
         while (pos < len && data[pos] == 0xFF) pos++;
@@ -799,6 +801,18 @@ int prepare_stream(const uint8_t *data, size_t len, Frame &f, StreamPlan &plan, 
                 if ((need_dc && dc_id[td] == UINT32_MAX) || (need_ac && ac_id[ta] == UINT32_MAX)) return RPH_ERR_INVALID_ARG;
                 sc.dc[i] = need_dc ? dc_id[td] : 0;
                 sc.ac[i] = need_ac ? ac_id[ta] : 0;
+            }
+            if (f.progressive) {
+                // The device walks the scans of a file side by side and applies the refinements when the coefficients are complete: that
+                // equals decoding scan after scan only for a progression as T.81 G.1.1.1.1 describes it -- every coefficient first coded
+                // once (Ah = 0), then refined bit by bit (Ah = the Al before).  Anything else (libjpeg: "bogus progression", a warning)
+                // stays with the host decoder, which takes the scans in file order whatever they say.
+                for (int i = 0; i < sc.ns; i++)
+                    for (int k = sc.ss; k <= sc.se; k++) {
+                        int8_t &bits = coef_bits[sc.ci[i]][k];
+                        if (sc.ah != (bits < 0 ? 0 : bits) || (bits < 0 && sc.ah != 0) || (bits >= 0 && sc.ah == 0)) return RPH_ERR_UNSUPPORTED;
+                        bits = (int8_t)sc.al;
+                    }
             }
             sc.restart_interval = f.restart_interval;
             sc.stream_off = (uint32_t)(o - out);

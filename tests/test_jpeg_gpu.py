@@ -336,6 +336,30 @@ def test_progressive_scans_follow_their_producers_across_many_batches(eng, oracl
         eng.jpeg_set_entropy(2)
 
 
+def test_progressions_the_standard_does_not_describe_stay_with_the_host_decoder(eng, oracle):
+    """the device walks the scans of a file side by side and applies refinements last, which equals scan-after-scan decoding only for
+    progressions as T.81 G.1.1.1.1 describes them; a band that is first-coded twice, a first scan after its refinement, a refinement whose
+    Ah is not the Al before (libjpeg: "bogus progression", decoded all the same) must give what the host decoder gives -- they are handed to it"""
+    bogus = [
+        [((0, 1, 2), 0, 0, 0, 0), ((0,), 1, 63, 0, 1), ((0,), 1, 63, 1, 0), ((0,), 1, 63, 0, 0), ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0)],   # luma first-coded again after its refinement
+        [((0, 1, 2), 0, 0, 0, 0), ((0,), 1, 63, 0, 2), ((0,), 1, 63, 1, 0), ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0)],                        # Ah = 1 after Al = 2
+        [((0, 1, 2), 0, 0, 0, 1), ((0, 1, 2), 0, 0, 0, 0), ((0,), 1, 63, 0, 0), ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0)],                    # DC first-coded twice
+        [((0, 1, 2), 0, 0, 0, 0), ((0,), 1, 20, 0, 0), ((0,), 10, 63, 0, 0), ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0)],                       # overlapping bands
+    ]
+    files = [ju.encode_progressive(np.asarray(ju.make_image(120 + 8 * k, 88, "RGB", seed=5000 + k)), script) for k, script in enumerate(bogus)]
+    files += [ju.encode_progressive(np.asarray(ju.make_image(96, 80, "RGB", seed=5100)), ju.SCRIPT_LIBJPEG)]
+    files = files * 20
+    eng.jpeg_set_entropy(0)
+    host = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    eng.jpeg_set_entropy(1)
+    try:
+        dev = eng.jpeg_pdq_hash_batch(files, threads=8, want_coeffs=True)
+    finally:
+        eng.jpeg_set_entropy(2)
+    assert np.array_equal(dev["status"], host["status"]) and np.array_equal(dev["valid"], host["valid"])
+    assert np.array_equal(dev["hash"], host["hash"]) and np.array_equal(dev["coeffs"].view(np.uint32), host["coeffs"].view(np.uint32))
+
+
 def test_progressive_scan_scripts_on_the_device(eng, oracle):
     """the device walk of progressive files on what Pillow cannot write (tests/jpeg_util.encode_progressive): bands refined in another order
     than they were first coded (the masks a refinement scan reads were last changed by atomics of an earlier scan), successive approximation
