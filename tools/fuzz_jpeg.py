@@ -62,7 +62,7 @@ def random_file():
 
 
 t_end = time.time() + budget
-rounds = files_total = damaged_total = 0
+rounds = files_total = damaged_total = damaged_status_differs = damaged_both_ok = damaged_hash_differs = 0
 while time.time() < t_end:
     files = [random_file() for _ in range(160)]
     flavour = rounds & 1
@@ -86,10 +86,19 @@ while time.time() < t_end:
             b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
         bad.append(bytes(b))
     if bad:
+        res = []
         for mode in (0, 1):
             eng.jpeg_set_entropy(mode)
             out = eng.jpeg_pdq_hash_batch(bad, flavour=flavour, threads=8)
             assert out["hash"].shape == (len(bad), 32)
+            res.append(out)
+        # how far the two decoders agree on damaged streams (reported, not required: what a decoder makes of a stream that breaks
+        # T.81 is its own business, but the fewer differences the better)
+        same_status = res[0]["status"] == res[1]["status"]
+        both_ok = (res[0]["status"] == 0) & (res[1]["status"] == 0)
+        damaged_status_differs += int((~same_status).sum())
+        damaged_both_ok += int(both_ok.sum())
+        damaged_hash_differs += int((both_ok & (res[0]["hash"] != res[1]["hash"]).any(axis=1)).sum())
         # the same damaged files, and truncated ones, with their streams cut into segments that synchronise on the device (a chain that runs
         # past the end of a scan must neither be trusted nor read behind the stream); then the defaults again
         trunc = []
@@ -110,4 +119,4 @@ while time.time() < t_end:
 eng.jpeg_set_entropy(2)
 eng.close()
 print(f"fuzz_jpeg seed {seed}: {files_total} random files agree bit for bit between host and device entropy decoding (both flavours); "
-      f"{damaged_total} damaged files survived both paths")
+      f"{damaged_total} damaged files survived both paths ({damaged_both_ok} of them decodable by both: {damaged_hash_differs} different hashes; {damaged_status_differs} with different status)")
