@@ -1115,12 +1115,13 @@ static_assert(sizeof(SegTable) == 288, "segment tables are packed");
 // LDS_TABLES as in the walk: the table probe is on the critical path of every symbol (from global memory it is a cache round trip per symbol:
 // 68 % of this kernel's wave-cycles were spent waiting, profiles/r03_pmc_jpeg_walk_sync.txt).
 constexpr int SYNC_BLOCK = 256;
-template <int LDS_TABLES>
+template <int LDS_TABLES, int MODE>
 __global__ void __launch_bounds__(SYNC_BLOCK) jpeg_sync_kernel(const uint8_t *__restrict__ streams, const HImage *__restrict__ imgs, const SegFile *__restrict__ files,
                                                        const uint32_t *__restrict__ seg_file, SegState *__restrict__ segs, SegOut2 *__restrict__ outs, uint32_t n_segs,
-                                                       uint32_t seg_bytes, SegTable *__restrict__ tables, int mode, int round, const rphj::DeviceLut *__restrict__ g_luts,
+                                                       uint32_t seg_bytes, SegTable *__restrict__ tables, int round, const rphj::DeviceLut *__restrict__ g_luts,
                                                        uint32_t n_luts)
 {
+    constexpr int mode = MODE;  // (a kernel per mode: round 0 carries nothing of the validation rounds' comparisons, and the other way round)
     __shared__ __attribute__((aligned(16))) rphj::DeviceLut s_luts[LDS_TABLES > 0 ? LDS_TABLES : 1];
     const rphj::DeviceLut *luts = LDS_TABLES > 0 ? s_luts : g_luts;
     const uint32_t u = blockIdx.x * SYNC_BLOCK + threadIdx.x;
@@ -1484,12 +1485,13 @@ int rph_jpeg_launch_segments(hipStream_t stream, const uint8_t *d_streams, const
     RPH_HIP_CHECK(hipMemsetAsync(d_segs, 0xFF, (size_t)n_segs * sizeof(SegState), stream));
     const dim3 grid((n_segs + SYNC_BLOCK - 1) / SYNC_BLOCK);
     auto sync = [&](int mode, int round) {
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, grid, dim3(SYNC_BLOCK), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_tables, round, d_luts, n_luts);
+        };
         if (n_luts <= (uint32_t)HUFF_LDS_TABLES)
-            hipLaunchKernelGGL(jpeg_sync_kernel<HUFF_LDS_TABLES>, grid, dim3(SYNC_BLOCK), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_tables,
-                               mode, round, d_luts, n_luts);
+            mode == 0 ? launch(jpeg_sync_kernel<HUFF_LDS_TABLES, 0>) : (mode == 1 ? launch(jpeg_sync_kernel<HUFF_LDS_TABLES, 1>) : launch(jpeg_sync_kernel<HUFF_LDS_TABLES, 2>));
         else
-            hipLaunchKernelGGL(jpeg_sync_kernel<0>, grid, dim3(SYNC_BLOCK), 0, stream, d_streams, d_images, d_files, d_seg_file, d_segs, d_outs, n_segs, seg_bytes, d_tables, mode, round,
-                               d_luts, n_luts);
+            mode == 0 ? launch(jpeg_sync_kernel<0, 0>) : (mode == 1 ? launch(jpeg_sync_kernel<0, 1>) : launch(jpeg_sync_kernel<0, 2>));
     };
     sync(0, 0);
     for (int r = 1; r <= rounds; r++) sync(1, r);
