@@ -138,3 +138,4 @@ int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HIm
 int rph_jpeg_launch_segments(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const SegFile *d_files, uint32_t n_files, SegState *d_segs,
                              uint32_t n_segs, uint32_t seg_bytes, void *d_work, int rounds, const rphj::DeviceLut *d_luts, uint32_t n_luts, HItem *d_items);
 size_t rph_jpeg_segment_work_bytes(uint32_t n_segs);  // of d_work
+void rph_jpeg_debug_segment_stats(hipStream_t stream, const void *d_work, uint32_t n_segs);  // (RPH_JPEG_TRACE=1)

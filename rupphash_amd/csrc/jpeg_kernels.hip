@@ -19,6 +19,8 @@
 //   RPH_JPEG_LIBJPEG         libjpeg-turbo's defaults (jidctint.c islow, jdsample.c fancy upsampling, jdcolor.c): pinned by the tests
 //                            against Pillow's decode of the reference's own JPEG files and of generated ones.
 
+#include <vector>
+
 #include "jpeg_device.h"
 #include "rph_internal.h"
 
@@ -1467,6 +1469,22 @@ int rph_jpeg_launch_prog(hipStream_t stream, const uint8_t *d_streams, const HIm
                        d_dcbits, d_status);
     RPH_HIP_CHECK(hipGetLastError());
     return RPH_OK;
+}
+
+// (RPH_JPEG_TRACE=1) what round 0 left: segments whose decode broke off, and how many MCU starts the others recorded
+void rph_jpeg_debug_segment_stats(hipStream_t stream, const void *d_work, uint32_t n_segs)
+{
+    std::vector<SegTable> t(n_segs);
+    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(t.data(), d_work, (size_t)n_segs * sizeof(SegTable), hipMemcpyDeviceToHost) != hipSuccess) return;
+    size_t broke = 0, none = 0, few = 0, full = 0;
+    for (const SegTable &x : t) {
+        if (x.out == SEG_NONE) broke++;
+        else if (x.n <= 1) none++;
+        else if (x.n < (uint32_t)SEG_MARKS) few++;
+        else full++;
+    }
+    fprintf(stderr, "[rph_jpeg] round 0 of %u segments: %zu broke off, %zu recorded only the boundary, %zu recorded 2..%d MCU starts, %zu recorded %d\n", n_segs, broke, none, few,
+            SEG_MARKS - 1, full, SEG_MARKS);
 }
 
 size_t rph_jpeg_segment_work_bytes(uint32_t n_segs) { return (size_t)n_segs * (sizeof(SegTable) + sizeof(SegOut2) + 4) + 64; }

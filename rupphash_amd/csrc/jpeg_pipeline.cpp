@@ -1069,6 +1069,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 RPH_TRY(rph_jpeg_launch_segments(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const SegFile *>(S.meta.d + off_segf),
                                                  (uint32_t)seg_files.size(), d_segs, n_segs, ctx->jpeg_seg_bytes, d_segtab, 8,
                                                  reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), reinterpret_cast<HItem *>(S.meta.d + off_items)));
+                if (tr) rph_jpeg_debug_segment_stats(s, d_segtab, n_segs);
             }
             lap(t_seg);
             // The coefficients start from zero -- unless the walk writes whole blocks and covers every block of the chunk: sequential files of
