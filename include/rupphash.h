@@ -375,9 +375,10 @@ int rph_jpeg_pdq_hash_one(rph_ctx *ctx, const uint8_t *data, size_t len, int fla
  *   RPH_JPEG_ENTROPY_DEVICE (1)  on the device, one file per lane: the host only copies the entropy bytes (stuffing undone) and the
  *                                compressed bytes cross PCIe; the walk of one file is serial (milliseconds), so this pays from
  *                                thousands of files per call;
- *   RPH_JPEG_ENTROPY_AUTO (2)    default: device from 2048 lanes per call (a sequential file is one lane, or one per restart
- *                                interval when it has restart markers, or one per segment of a long stream without them; a
- *                                progressive file is one lane), host below;
+ *   RPH_JPEG_ENTROPY_AUTO (2)    default: sequential files on the device from 512 lanes per call (a file is one lane, or one per
+ *                                restart interval when it has restart markers, or one per 8 KB of a stream without them that is
+ *                                long enough for segments), host below; progressive files on the device when the host threads
+ *                                would need longer for all of them than the device for the longest (~0.6 us per byte);
  *   RPH_JPEG_ENTROPY_DEVICE_SEQUENTIAL (3)  as DEVICE, but progressive files stay with the host threads (tests, A/B timing).
  * Same results either way. */
 #define RPH_JPEG_ENTROPY_HOST 0
