@@ -672,7 +672,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
     // 8 chunks 81 k, 16 chunks 86 k, 32 chunks 71 k).
     if (by_segments && 0.65e-6 * (double)max_len <= 0.08) min_chunk = (size_t)4 << 30, parts = 16;
     if (const char *e = getenv("RPH_JPEG_CHUNK_GB")) min_chunk = (size_t)atoi(e) << 30;  // experiments
-    if (const char *e = getenv("RPH_JPEG_PARTS")) parts = (size_t)atoi(e);
+    if (const char *e = getenv("RPH_JPEG_PARTS")) parts = (size_t)std::max(1, atoi(e));
     const size_t chunk_target = std::min(need, std::max(need / parts + 128, min_chunk));
     const bool single = need <= chunk_target && need <= budget;
     const int lanes = single ? 1 : (int)std::min<size_t>(JPEG_LANES, (need + chunk_target - 1) / chunk_target);  // chunks in flight
