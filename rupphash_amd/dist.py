@@ -312,3 +312,84 @@ def hash_and_group_device(eng, images, n_total, similarity, dist=None, variants=
     if timings is not None:
         timings["total_s"] = time.perf_counter() - t0
     return groups, info
+
+
+def scan_jpeg_files_and_group(eng, files, n_total, similarity, dist=None, flavour=0, threads=0, edge_cap=1 << 20, timings=None):
+    """JPEG files in host memory -> decode + PDQ hash on this rank's GPU -> all-gather -> sweep -> groups: the reference's scan
+    (scanner.rs:1146-1551: load_image_fast + generate_pdq_features for every file on the rayon pool, then group_files_generic) with
+    the files sharded over the ranks of a node, one process per GPU.
+
+    files: THIS rank's shard (shard_range(n_total, rank, world)) of the file sequence, a list of JPEG byte strings.  Every rank
+    decodes and hashes its own files with rph_jpeg_pdq_hash_batch (entropy decoding on the device when the shard is large enough,
+    hash + quality + the 8 dihedral hashes per file); the one exchange step is an all-gather of the 256-byte dihedral blocks, the
+    1-byte low-confidence flags (scanner.rs:1588-1594) and the 1-byte validity flags; every rank then sweeps its share of the block
+    pairs (rph_hamming_variant_pairs_dev) and rank 0 unites the edges.  A file that cannot be decoded takes part in nothing, as in
+    the reference, where it never gets a hash: its rows are replaced by a pattern of its own (a function of its index) that lies
+    ~128 bits from everything, and it is listed in info["unreadable"].
+    Returns (groups or None, info): groups on rank 0 (connected components of more than one file, members ascending, by first member)."""
+    import time
+
+    import torch
+
+    world = 1 if dist is None else dist.get_world_size()
+    rank = 0 if dist is None else dist.get_rank()
+    lo, hi = shard_range(n_total, rank, world)
+    n_local = hi - lo
+    assert len(files) == n_local, (len(files), lo, hi)
+    dev = torch.device("cuda", eng.device)
+    t0 = time.perf_counter()
+    if n_local:
+        out = eng.jpeg_pdq_hash_batch(files, flavour=flavour, threads=threads, want_quality=True, want_dihedral=True)
+        dih, quality, valid = out["dihedral"], out["quality"], out["valid"].astype(np.uint8)
+    else:
+        dih, quality, valid = np.zeros((0, 8, 32), np.uint8), np.zeros(0, np.float32), np.zeros(0, np.uint8)
+    for k in np.nonzero(valid == 0)[0]:  # unreadable (or below 5 px): unmatchable rows of its own
+        dih[k, :, :] = np.random.default_rng(0x9E3779B97F4A7C15 ^ int(lo + k)).integers(0, 256, 32, dtype=np.uint8)
+    stored = np.clip(np.floor(quality.astype(np.float32) * np.float32(100.0) + np.float32(0.5)), 0, 100)
+    low = ((stored < 50) | (valid == 0)).astype(np.uint8)
+    if timings is not None:
+        timings["decode_and_hash_ms"] = (time.perf_counter() - t0) * 1e3
+        t1 = time.perf_counter()
+    # (the library reads a null stream handle as "the context's own stream", which torch's default stream is not ordered with: a side
+    # stream carries the copies, the collectives and the sweep)
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        d_dih = torch.from_numpy(np.ascontiguousarray(dih.reshape(n_local, 256))).to(dev)
+        d_low = torch.from_numpy(low.reshape(n_local, 1)).to(dev)
+        d_valid = torch.from_numpy(valid.reshape(n_local, 1)).to(dev)
+        all_dih = all_gather_rows(d_dih, n_total, dist, dev).reshape(n_total, 8, 32).contiguous()
+        all_low = all_gather_rows(d_low, n_total, dist, dev).reshape(n_total).contiguous()
+        all_valid = all_gather_rows(d_valid, n_total, dist, dev).reshape(n_total)
+        all_hash = all_dih[:, 0, :].contiguous()
+        if timings is not None:
+            side.synchronize()
+            timings["allgather_ms"] = (time.perf_counter() - t1) * 1e3
+            t2 = time.perf_counter()
+        cap = int(edge_cap)
+        while True:
+            d_edges = torch.empty((cap, EDGE_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+            d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+            eng.hamming_variant_pairs_dev(all_dih.data_ptr(), 8, all_hash.data_ptr(), n_total, similarity, d_edges.data_ptr(), cap, d_count.data_ptr(),
+                                          d_low_conf=all_low.data_ptr(), part=rank, nparts=world, stream=side.cuda_stream)
+            found = int(d_count.item())
+            if found <= cap:
+                break
+            cap = found + found // 8 + 1024  # rare: more edges than expected, sweep again into a buffer that fits
+        if timings is not None:
+            timings["sweep_ms"] = (time.perf_counter() - t2) * 1e3
+        local_edges = d_edges[:found].cpu().numpy().reshape(-1).view(EDGE_DTYPE) if found else np.zeros(0, EDGE_DTYPE)
+        unreadable = [int(i) for i in np.nonzero(all_valid.cpu().numpy() == 0)[0]]
+    torch.cuda.current_stream(dev).wait_stream(side)
+    merged = gather_edges(local_edges, dist, dst=0, device=dev)
+    info = {"n_local": n_local, "edges_local": found, "ranks_in_collective": world}
+    if rank != 0:
+        return None, info
+    info["edges_total"] = int(len(merged))
+    info["unreadable"] = unreadable
+    groups = eng.union_find_groups(merged, n_total)
+    if timings is not None:
+        timings["total_s"] = time.perf_counter() - t0
+    return groups, info

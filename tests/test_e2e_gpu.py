@@ -158,3 +158,46 @@ def test_hash_and_group_three_ranks_share_one_gpu(oracle, e2e_expected, tmp_path
         res = json.load(f)
     assert res["world"] == world and res["info"]["ranks_in_collective"] == world
     assert res["groups"] == want_groups and res["info"]["edges_total"] == want_cmp
+
+
+N_JPEG, SIM_JPEG = 90, 40
+
+
+def test_scan_of_jpeg_files_sharded_over_three_ranks(eng, oracle, tmp_path):
+    """the reference's scan with JPEG inputs (scanner.rs:1146-1551) as rupphash_amd.dist.scan_jpeg_files_and_group: every rank decodes and
+    hashes its shard of the files on the GPU, one all-gather of dihedral blocks and flags, every rank sweeps its share, rank 0 groups.
+    90 files (pairs of one picture at two qualities, some progressive, one unreadable) on one rank in this process and on three ranks
+    that share the GPU (gloo) must give the groups the single-process production path gives (rph_jpeg_pdq_hash_batch over all files +
+    group_files_pdq), with the unreadable file in no group."""
+    from dist_jpeg_worker import make_files
+    from rupphash_amd import dist as D
+    from rupphash_amd import scanner
+
+    files = make_files(eng, 0, N_JPEG)
+    out = eng.jpeg_pdq_hash_batch(files, threads=4, want_quality=True, want_coeffs=True)
+    assert out["valid"].sum() == N_JPEG - 1 and out["valid"][7] == 0
+    ok = [k for k in range(N_JPEG) if out["valid"][k]]
+    want, _ = scanner.group_with_pdqhash(out["hash"][ok], SIM_JPEG, coefficients=out["coeffs"][ok], has_features=np.ones(len(ok), bool),
+                                         quality=[scanner.stored_quality(q) for q in out["quality"][ok]], engine=eng)
+    want = [[ok[i] for i in g] for g in want]
+    assert len(want) >= N_JPEG // 2 - 2 and all(len(g) >= 2 for g in want)  # (the pairs: same picture at quality 90 and 60)
+    groups, info = D.scan_jpeg_files_and_group(eng, files, N_JPEG, SIM_JPEG, None, threads=4)
+    assert groups == want and info["unreadable"] == [7]
+    world, port, res_file = 3, _free_port(), str(tmp_path / "jpeg_groups.json")
+    worker = os.path.join(HERE, "dist_jpeg_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(N_JPEG), str(SIM_JPEG), "gloo", res_file], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    with open(res_file) as f:
+        res = json.load(f)
+    assert res["world"] == world and res["info"]["ranks_in_collective"] == world
+    assert res["groups"] == want and res["info"]["unreadable"] == [7]
