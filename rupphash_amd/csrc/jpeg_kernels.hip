@@ -158,19 +158,14 @@ __device__ constexpr int unzigzag(int n)
     return 0;
 }
 
-// grid: x = groups of 256 blocks of a plane, y = plane.  Lane = block: neighbouring lanes write neighbouring 8-byte row segments.
+// One block: its 64 coefficients (with the refinements of a progressive file's scans added, below) -> 8 rows of 8 samples.
 // Planes of progressive files walked on the device carry the records of their AC refinement scans (jpeg_device.h, PCorr): the
 // corrections are added here, scan by scan in file order, by T.81 G.1.2.3's rule as libjpeg applies it -- a coefficient with history whose
 // correction bit is set moves away from zero by 1 << Al, unless that bit of it is set already (a damaged stream).
 template <int FL>
-__global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t *__restrict__ coef, const uint16_t *__restrict__ qts, const JPlane *__restrict__ planes,
-                                                        uint8_t *__restrict__ out, const PRef *__restrict__ refs, const PCorr *__restrict__ corr,
-                                                        const uint8_t *__restrict__ dcbits)
+__device__ __forceinline__ void idct_block(const int16_t *__restrict__ coef, const uint16_t *__restrict__ qts, const JPlane &pl, uint32_t b, uint32_t bx, uint32_t by,
+                                           const PRef *__restrict__ refs, const PCorr *__restrict__ corr, const uint8_t *__restrict__ dcbits, uint2 (&rows)[8])
 {
-    const JPlane pl = planes[blockIdx.y];
-    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= pl.blocks_w * pl.blocks_h) return;
-    const uint32_t bx = b % pl.blocks_w, by = b / pl.blocks_w;
     const uint4 *src = reinterpret_cast<const uint4 *>(coef + (pl.first_block + b) * 64);
     const uint16_t *qt = qts + (size_t)pl.qt * 64;  // plane-uniform: scalar loads
     int32_t c[64];
@@ -215,7 +210,6 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t *__restric
         else
             idct_stb<512, 10>(c[x], c[8 + x], c[16 + x], c[24 + x], c[32 + x], c[40 + x], c[48 + x], c[56 + x]);
     }
-    uint8_t *dst = out + pl.out_off + (size_t)(by * 8) * pl.pitch + bx * 8;
 #pragma unroll
     for (int y = 0; y < 8; y++) {
         int32_t *r = c + 8 * y;
@@ -237,11 +231,27 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t *__restric
                 v[x] = clamp8(t);
             }
         }
-        uint2 w;
-        w.x = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
-        w.y = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
-        *reinterpret_cast<uint2 *>(dst + (size_t)y * pl.pitch) = w;
+        rows[y].x = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+        rows[y].y = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
     }
+}
+
+// grid: x = groups of 256 blocks of a plane, y = plane.  Lane = block: neighbouring lanes write neighbouring 8-byte row segments.
+// (The planes of an image that the fused kernel below takes are skipped.)
+template <int FL>
+__global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t *__restrict__ coef, const uint16_t *__restrict__ qts, const JPlane *__restrict__ planes,
+                                                        uint8_t *__restrict__ out, const PRef *__restrict__ refs, const PCorr *__restrict__ corr,
+                                                        const uint8_t *__restrict__ dcbits)
+{
+    const JPlane pl = planes[blockIdx.y];
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (pl.fused || b >= pl.blocks_w * pl.blocks_h) return;
+    const uint32_t bx = b % pl.blocks_w, by = b / pl.blocks_w;
+    uint2 rows[8];
+    idct_block<FL>(coef, qts, pl, b, bx, by, refs, corr, dcbits, rows);
+    uint8_t *dst = out + pl.out_off + (size_t)(by * 8) * pl.pitch + bx * 8;
+#pragma unroll
+    for (int y = 0; y < 8; y++) *reinterpret_cast<uint2 *>(dst + (size_t)y * pl.pitch) = rows[y];
 }
 
 template <int FL>
@@ -271,8 +281,9 @@ __device__ __forceinline__ void bytes4(uint32_t u, int *d)
 //   libjpeg-turbo (jdsample.c): h2v1 / h2v2 / h1v2 "fancy" triangle filters; columns are replicated instead when the plane has <= 2 of them
 //   zune-jpeg (recalled): (3 a + b + 2) >> 2 vertically, then the same horizontally on the result; the first and last column are copied
 template <int FL>
-__device__ __forceinline__ void chroma8(const uint8_t *__restrict__ plane, int pitch, int n, int rows, int x0, int y, int hs, int vs, int (&out)[8])
+__device__ __forceinline__ void chroma8(const uint8_t *__restrict__ plane, int pitch, int n, int rows, int x0, int y, int hs, int vs, int (&out)[8], int cols = 0)
 {
+    if (cols == 0) cols = pitch;  // samples per row of the plane (the fused kernel reads a tile of it in LDS: another pitch, the same columns)
     int r = vs == 2 ? (y >> 1) : y, rr = vs == 2 ? ((y & 1) ? r + 1 : r - 1) : r;
     r = r >= rows ? rows - 1 : r;  // (only rows of the padding, beyond the image, can exceed the plane's samples)
     rr = rr < 0 ? 0 : (rr >= rows ? rows - 1 : rr);  // the edge row repeats above and below (jdmainct.c context rows)
@@ -298,7 +309,7 @@ __device__ __forceinline__ void chroma8(const uint8_t *__restrict__ plane, int p
     int a[6], b[6];
     bytes4(*reinterpret_cast<const uint32_t *>(pr + c0), a + 1);
     bytes4(*reinterpret_cast<const uint32_t *>(prr + c0), b + 1);
-    const int cl = c0 > 0 ? c0 - 1 : 0, cr = c0 + 4 < pitch ? c0 + 4 : pitch - 1;
+    const int cl = c0 > 0 ? c0 - 1 : 0, cr = c0 + 4 < cols ? c0 + 4 : cols - 1;
     a[0] = pr[cl], a[5] = pr[cr], b[0] = prr[cl], b[5] = prr[cr];
     if (FL == RPH_JPEG_LIBJPEG && n <= 2) {  // h2v1_upsample / h2v2_upsample: replication
 #pragma unroll
@@ -340,7 +351,7 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const uint8_t *__restri
     const JImage im = imgs[blockIdx.y];
     const uint32_t w8 = (im.w + 7) / 8;
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= w8 * im.h) return;
+    if (im.fused || t >= w8 * im.h) return;
     const int y = (int)(t / w8), x0 = (int)(t % w8) * 8;
     const uint2 yy = *reinterpret_cast<const uint2 *>(planes + im.plane_off[0] + (size_t)y * im.pitch[0] + x0);  // planes are padded to whole blocks
     uint8_t *dst = out + im.out_off + (size_t)y * im.out_stride;
@@ -371,6 +382,79 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const uint8_t *__restri
     for (int q = 0; q < 3; q++) {
         const uint32_t *p = px + 8 * q;
         d64[q] = make_uint2(p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24), p[4] | (p[5] << 8) | (p[6] << 16) | (p[7] << 24));
+    }
+}
+
+// IDCT + chroma upsampling + colour + Rec.601 luma of one tile of a 4:2:0 image whose pixels only the hasher reads: 8 x 4 MCUs = 128 x 64
+// luma samples and, per chroma plane, the 8 x 4 blocks under them with a ring of blocks around (the upsampling filters look one sample
+// beyond the tile; the ring's blocks are transformed whole).  248 of the 256 lanes transform one block each into LDS; then every lane makes
+// 4 x 8 pixels out of LDS with the very functions of the two-kernel path (chroma8, ycc_to_rgb), so the results are the same bytes.  The
+// sample planes are never written: 416 -> ~300 bytes of traffic per block.
+constexpr int FT_MX = 8, FT_MY = 4;                                   // MCUs per tile
+constexpr int FT_LW = FT_MX * 16, FT_LH = FT_MY * 16;                 // luma samples
+constexpr int FT_CBW = FT_MX + 2, FT_CBH = FT_MY + 2;                 // chroma blocks with the ring
+constexpr int FT_CW = FT_CBW * 8, FT_CH = FT_CBH * 8;                 // chroma samples in LDS
+template <int FL>
+__global__ void __launch_bounds__(256) jpeg_fused_kernel(const int16_t *__restrict__ coef, const uint16_t *__restrict__ qts, const JPlane *__restrict__ planes,
+                                                         const JImage *__restrict__ imgs, uint8_t *__restrict__ out, const PRef *__restrict__ refs,
+                                                         const PCorr *__restrict__ corr, const uint8_t *__restrict__ dcbits)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_y[FT_LW * FT_LH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_c[2][FT_CW * FT_CH];
+    const JImage im = imgs[blockIdx.y];
+    if (!im.fused) return;
+    const uint32_t tiles_x = (im.mcus_x + FT_MX - 1) / FT_MX, tiles_y = (im.mcus_y + FT_MY - 1) / FT_MY;
+    if (blockIdx.x >= tiles_x * tiles_y) return;
+    const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const uint32_t t = threadIdx.x;
+    // ---- one block per lane: 16 x 8 luma blocks, then 10 x 6 blocks of Cb, then of Cr
+    {
+        uint32_t comp, lbx, lby;  // component; block position in the tile's LDS grid
+        if (t < 128)
+            comp = 0, lbx = t & 15, lby = t >> 4;
+        else {
+            const uint32_t j = t - 128;
+            comp = 1 + j / (FT_CBW * FT_CBH), lbx = (j % (FT_CBW * FT_CBH)) % FT_CBW, lby = (j % (FT_CBW * FT_CBH)) / FT_CBW;
+        }
+        if (comp < 3) {
+            const JPlane pl = planes[im.first_plane + comp];
+            // position in the plane's block grid (the chroma grid of LDS begins one block before the tile)
+            const int bx = comp == 0 ? (int)(tx * FT_MX * 2 + lbx) : (int)(tx * FT_MX + lbx) - 1, by = comp == 0 ? (int)(ty * FT_MY * 2 + lby) : (int)(ty * FT_MY + lby) - 1;
+            if (bx >= 0 && by >= 0 && bx < (int)pl.blocks_w && by < (int)pl.blocks_h) {
+                uint2 rows[8];
+                idct_block<FL>(coef, qts, pl, (uint32_t)by * pl.blocks_w + (uint32_t)bx, (uint32_t)bx, (uint32_t)by, refs, corr, dcbits, rows);
+                uint8_t *dst = comp == 0 ? s_y + (lby * 8) * FT_LW + lbx * 8 : s_c[comp - 1] + (lby * 8) * FT_CW + lbx * 8;
+                const int pitch = comp == 0 ? FT_LW : FT_CW;
+#pragma unroll
+                for (int y = 0; y < 8; y++) *reinterpret_cast<uint2 *>(dst + y * pitch) = rows[y];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 8 pixels of a row per lane and turn, as jpeg_color_kernel makes them; the chroma tiles stand for their planes (a pointer such that
+    // the plane's coordinates land in the tile: the filters clamp to the plane's own edges, which lie inside the tile or its ring)
+    const int cy0 = (int)(ty * FT_MY * 8) - 8, cx0 = (int)(tx * FT_MX * 8) - 8;  // plane coordinates of the chroma tiles' first sample
+    const uint8_t *vcb = s_c[0] - (cy0 * FT_CW + cx0), *vcr = s_c[1] - (cy0 * FT_CW + cx0);
+    const int cols = (int)im.pitch[1];
+    uint8_t *img_out = out + im.out_off;
+#pragma unroll
+    for (int k = 0; k < (FT_LW / 8) * FT_LH / 256; k++) {
+        const uint32_t g = t + 256 * k, row = g / (FT_LW / 8), xg = g % (FT_LW / 8);
+        const int y = (int)(ty * FT_LH + row), x0 = (int)(tx * FT_LW + xg * 8);
+        if (y >= (int)im.h || x0 >= (int)im.w) continue;
+        const uint2 yy = *reinterpret_cast<const uint2 *>(s_y + row * FT_LW + xg * 8);
+        int ys[8], cb[8], cr[8];
+        bytes4(yy.x, ys), bytes4(yy.y, ys + 4);
+        chroma8<FL>(vcb, FT_CW, (int)im.cw, (int)im.ch, x0, y, 2, 2, cb, cols);
+        chroma8<FL>(vcr, FT_CW, (int)im.cw, (int)im.ch, x0, y, 2, 2, cr, cols);
+        uint32_t l[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int r, gg, b;
+            ycc_to_rgb<FL>(ys[i], cb[i], cr[i], r, gg, b);
+            l[i] = (299u * (uint32_t)r + 587u * (uint32_t)gg + 114u * (uint32_t)b + 500u) / 1000u;  // to_luma601 (pdqhash.rs:268-284)
+        }
+        *reinterpret_cast<uint2 *>(img_out + (size_t)y * im.out_stride + x0) = make_uint2(l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24), l[4] | (l[5] << 8) | (l[6] << 16) | (l[7] << 24));
     }
 }
 
@@ -1426,6 +1510,19 @@ bool rph_jpeg_walk_writes_whole_blocks(uint32_t n_items)
 {
     static const int stage_env = getenv("RPH_JPEG_WALK_STAGE") ? atoi(getenv("RPH_JPEG_WALK_STAGE")) : -1;  // experiments: 0 never, 1 always
     return stage_env >= 0 ? stage_env != 0 : n_items >= 131072u;  // (staged: 195 k lanes +6 %, 237 k lanes +9 %; 59 k lanes -5 %)
+}
+
+int rph_jpeg_launch_fused(int flavour, uint32_t max_tiles, uint32_t n_images, hipStream_t stream, const int16_t *d_coef, const uint16_t *d_tables, const JPlane *d_planes,
+                          const JImage *d_images, uint8_t *d_pixels, const PRef *d_refs, const PCorr *d_corr, const uint8_t *d_dcbits)
+{
+    if (max_tiles == 0 || n_images == 0) return RPH_OK;
+    const dim3 grid(max_tiles, n_images);
+    if (flavour == RPH_JPEG_LIBJPEG)
+        hipLaunchKernelGGL(jpeg_fused_kernel<RPH_JPEG_LIBJPEG>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_images, d_pixels, d_refs, d_corr, d_dcbits);
+    else
+        hipLaunchKernelGGL(jpeg_fused_kernel<RPH_JPEG_ZUNE>, grid, dim3(256), 0, stream, d_coef, d_tables, d_planes, d_images, d_pixels, d_refs, d_corr, d_dcbits);
+    RPH_HIP_CHECK(hipGetLastError());
+    return RPH_OK;
 }
 
 int rph_jpeg_launch_walk(hipStream_t stream, const uint8_t *d_streams, const HImage *d_images, const HItem *d_items, const uint32_t *d_order, uint32_t n_ordered,

@@ -383,6 +383,8 @@ int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first
     sub_starts.clear();
     sub_starts.push_back(0);
     size_t plane_bytes = 0, out_bytes = 0, sub_blocks = 0, sub_images = 0;
+    uint32_t sub_first_plane = 0;
+    static const bool fuse = !getenv("RPH_JPEG_NO_FUSED");  // (A/B: the two-kernel reconstruction for every image)
     for (size_t r = 0; r < m; r++) {
         Job &j = jobs[idx[first + r]];
         if (j.status != RPH_OK) continue;
@@ -393,12 +395,19 @@ int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first
             sub_starts.push_back(r);
             plane_bytes = out_bytes = sub_blocks = 0;
             sub_images = 0;
+            sub_first_plane = D.n_planes;
         }
         sub_blocks += f.total_blocks;
         sub_images++;
         JImage im;
         memset(&im, 0, sizeof im);
         D.plane_of[r] = D.n_planes;
+        // 4:2:0 and only the hasher reads the pixels: IDCT + upsampling + colour in one kernel, the sample planes never exist
+        const bool fused = fuse && f.ncomp == 3 && out_channels(f, rgb_wanted) == 1 && f.comp[0].H == 2 && f.comp[0].V == 2 && f.comp[1].H == 1 && f.comp[1].V == 1 &&
+                           f.comp[2].H == 1 && f.comp[2].V == 1;
+        im.fused = fused;
+        im.first_plane = D.n_planes - sub_first_plane;
+        im.mcus_x = f.mcus_x, im.mcus_y = f.mcus_y;
         for (int c = 0; c < f.ncomp; c++) {
             const rphj::Comp &kc = f.comp[c];
             JPlane pl;
@@ -411,6 +420,7 @@ int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first
             pl.real_bw = kc.real_bw;
             pl.real_bh = kc.real_bh;
             pl.ref_first = pl.ref_count = 0;
+            pl.fused = fused, pl.pad_ = 0;
             memcpy(hq + (size_t)D.n_planes * 64, f.qt[kc.tq], 128);
             im.plane_off[c] = plane_bytes;
             im.pitch[c] = pl.pitch;
@@ -458,8 +468,18 @@ int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, Jobs &jobs, 
     const JPlane *dp = reinterpret_cast<const JPlane *>(S.meta.d + D.off_planes) + p0;
     const JImage *di = reinterpret_cast<const JImage *>(S.meta.d + D.off_images) + i0;
     const uint16_t *dq = reinterpret_cast<const uint16_t *>(S.meta.d + D.off_tables);
-    RPH_TRY(rph_jpeg_launch_idct(flavour, max_blocks, p1 - p0, s, d_coef, dq, dp, P.d_planes[b], D.d_refs, D.d_corr, D.d_dcbits));
-    RPH_TRY(rph_jpeg_launch_color(flavour, max_groups, i1 - i0, s, P.d_planes[b], di, P.d_out[b]));
+    const JImage *hi_all = reinterpret_cast<const JImage *>(S.meta.h + D.off_images);
+    uint32_t n_fused = 0, max_tiles = 0;
+    for (uint32_t q = i0; q < i1; q++)
+        if (hi_all[q].fused) {
+            n_fused++;
+            max_tiles = std::max(max_tiles, ((hi_all[q].mcus_x + 7) / 8) * ((hi_all[q].mcus_y + 3) / 4));
+        }
+    if (n_fused < i1 - i0) {  // (the plane kernels skip the images the fused kernel takes)
+        RPH_TRY(rph_jpeg_launch_idct(flavour, max_blocks, p1 - p0, s, d_coef, dq, dp, P.d_planes[b], D.d_refs, D.d_corr, D.d_dcbits));
+        RPH_TRY(rph_jpeg_launch_color(flavour, max_groups, i1 - i0, s, P.d_planes[b], di, P.d_out[b]));
+    }
+    if (n_fused) RPH_TRY(rph_jpeg_launch_fused(flavour, max_tiles, i1 - i0, s, d_coef, dq, dp, di, P.d_out[b], D.d_refs, D.d_corr, D.d_dcbits));
     if (!out.want_hash) return RPH_OK;
     // hash runs of equal geometry where the pixels lie (generate_pdq_features, scanner.rs:1410)
     ResView R(S.res.d, S.res_images);
