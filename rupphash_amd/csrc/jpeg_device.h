@@ -29,8 +29,8 @@ struct JImage {
     uint32_t cw, ch;        // chroma samples the upsampler may use: real component samples (libjpeg) or the padded plane (zune)
     uint32_t out_stride;    // bytes per output row: channels * align8(w)
     uint32_t luma_out;      // three components, but the hasher is the only reader: write Rec.601 luma (what to_luma601 makes of the RGB) instead of Rgb8
-    uint32_t fused;         // 4:2:0 with luma_out: jpeg_fused_kernel takes the image (its three planes are first_plane ..)
-    uint32_t first_plane, mcus_x, mcus_y;
+    uint32_t fused;         // three components with luma_out: jpeg_fused_kernel takes the image (its three planes are first_plane ..)
+    uint32_t first_plane, tiles_x, tiles_y;  // tiles of 16 x 8 luma blocks
 };
 
 struct HComp {
@@ -119,9 +119,9 @@ constexpr int HUFF_LDS_TABLES = 8;  // the walk keeps the chunk's Huffman tables
 int rph_jpeg_launch_idct(int flavour, uint32_t max_blocks, uint32_t n_planes, hipStream_t stream, const int16_t *d_coef, const uint16_t *d_tables, const JPlane *d_planes,
                          uint8_t *d_samples, const PRef *d_refs = nullptr, const PCorr *d_corr = nullptr, const uint8_t *d_dcbits = nullptr);
 int rph_jpeg_launch_color(int flavour, uint32_t max_groups, uint32_t n_images, hipStream_t stream, const uint8_t *d_samples, const JImage *d_images, uint8_t *d_pixels);
-// Images marked `fused` (three components, 4:2:0, only the hasher reads them): IDCT of a tile of 8 x 4 MCUs with a ring of chroma blocks
-// around it into LDS, upsampling + colour + Rec.601 luma out of LDS -- the sample planes never exist in memory.  max_tiles = the largest
-// ceil(mcus_x / 8) * ceil(mcus_y / 4) of the images; d_planes / d_images as for the two kernels above (same sub-batch).
+// Images marked `fused` (three components, only the hasher reads them): IDCT of a tile of 16 x 8 luma blocks and of the chroma blocks under
+// them with a ring of blocks around into LDS, upsampling + colour + Rec.601 luma out of LDS -- the sample planes never exist in memory.
+// max_tiles = the largest tiles_x * tiles_y of the images; d_planes / d_images as for the two kernels above (same sub-batch).
 int rph_jpeg_launch_fused(int flavour, uint32_t max_tiles, uint32_t n_images, hipStream_t stream, const int16_t *d_coef, const uint16_t *d_tables, const JPlane *d_planes,
                           const JImage *d_images, uint8_t *d_pixels, const PRef *d_refs = nullptr, const PCorr *d_corr = nullptr, const uint8_t *d_dcbits = nullptr);
 // d_order: the first n_ordered items in the order the lanes take them (longest first); items n_ordered .. n_items - 1 are taken as they lie

@@ -385,56 +385,56 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const uint8_t *__restri
     }
 }
 
-// IDCT + chroma upsampling + colour + Rec.601 luma of one tile of a 4:2:0 image whose pixels only the hasher reads: 8 x 4 MCUs = 128 x 64
-// luma samples and, per chroma plane, the 8 x 4 blocks under them with a ring of blocks around (the upsampling filters look one sample
-// beyond the tile; the ring's blocks are transformed whole).  248 of the 256 lanes transform one block each into LDS; then every lane makes
-// 4 x 8 pixels out of LDS with the very functions of the two-kernel path (chroma8, ycc_to_rgb), so the results are the same bytes.  The
-// sample planes are never written: 416 -> ~300 bytes of traffic per block.
-constexpr int FT_MX = 8, FT_MY = 4;                                   // MCUs per tile
-constexpr int FT_LW = FT_MX * 16, FT_LH = FT_MY * 16;                 // luma samples
-constexpr int FT_CBW = FT_MX + 2, FT_CBH = FT_MY + 2;                 // chroma blocks with the ring
-constexpr int FT_CW = FT_CBW * 8, FT_CH = FT_CBH * 8;                 // chroma samples in LDS
+// IDCT + chroma upsampling + colour + Rec.601 luma of one tile of a three-component image whose pixels only the hasher reads (luma
+// sampled 1 or 2 times the chroma in either direction: 4:2:0, 4:2:2, 4:4:0, 4:4:4).  A tile is 16 x 8 luma blocks = 128 x 64 samples and,
+// per chroma plane, the blocks under them with a ring of blocks around (the upsampling filters look one sample beyond the tile; the ring's
+// blocks are transformed whole).  The lanes transform one block each (all at once for 4:2:0, in two turns for the finer chroma grids) into
+// LDS; then every lane makes 4 x 8 pixels out of LDS with the very functions of the two-kernel path (chroma8, ycc_to_rgb), so the results are
+// the same bytes.  The sample planes are never written: 416 -> ~300 bytes of traffic per block at 4:2:0.
+constexpr int FT_LBW = 16, FT_LBH = 8;                                // luma blocks per tile
+constexpr int FT_LW = FT_LBW * 8, FT_LH = FT_LBH * 8;                 // luma samples
+constexpr int FT_CMAX = (FT_LBW + 2) * 8 * (FT_LBH + 2) * 8;          // chroma samples in LDS at most (4:4:4: 18 x 10 blocks)
 template <int FL>
 __global__ void __launch_bounds__(256) jpeg_fused_kernel(const int16_t *__restrict__ coef, const uint16_t *__restrict__ qts, const JPlane *__restrict__ planes,
                                                          const JImage *__restrict__ imgs, uint8_t *__restrict__ out, const PRef *__restrict__ refs,
                                                          const PCorr *__restrict__ corr, const uint8_t *__restrict__ dcbits)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_y[FT_LW * FT_LH];
-    __shared__ __attribute__((aligned(16))) uint8_t s_c[2][FT_CW * FT_CH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_c[2][FT_CMAX];
     const JImage im = imgs[blockIdx.y];
     if (!im.fused) return;
-    const uint32_t tiles_x = (im.mcus_x + FT_MX - 1) / FT_MX, tiles_y = (im.mcus_y + FT_MY - 1) / FT_MY;
-    if (blockIdx.x >= tiles_x * tiles_y) return;
-    const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    if (blockIdx.x >= im.tiles_x * im.tiles_y) return;
+    const uint32_t tx = blockIdx.x % im.tiles_x, ty = blockIdx.x / im.tiles_x;
     const uint32_t t = threadIdx.x;
-    // ---- one block per lane: 16 x 8 luma blocks, then 10 x 6 blocks of Cb, then of Cr
-    {
+    const uint32_t hs = im.hs, vs = im.vs;
+    const uint32_t cbw = FT_LBW / hs + 2, cbh = FT_LBH / vs + 2, cpitch = cbw * 8;  // chroma blocks with the ring; samples per LDS row
+    const int cbx0 = (int)(tx * (FT_LBW / hs)) - 1, cby0 = (int)(ty * (FT_LBH / vs)) - 1;  // the chroma grid of LDS begins one block before the tile
+    // ---- one block per lane and turn: 16 x 8 luma blocks, then cbw x cbh blocks of Cb, then of Cr
+    const uint32_t n_blocks = FT_LBW * FT_LBH + 2 * cbw * cbh;
+    for (uint32_t l = t; l < n_blocks; l += 256) {
         uint32_t comp, lbx, lby;  // component; block position in the tile's LDS grid
-        if (t < 128)
-            comp = 0, lbx = t & 15, lby = t >> 4;
+        if (l < FT_LBW * FT_LBH)
+            comp = 0, lbx = l % FT_LBW, lby = l / FT_LBW;
         else {
-            const uint32_t j = t - 128;
-            comp = 1 + j / (FT_CBW * FT_CBH), lbx = (j % (FT_CBW * FT_CBH)) % FT_CBW, lby = (j % (FT_CBW * FT_CBH)) / FT_CBW;
+            const uint32_t j = l - FT_LBW * FT_LBH, k = j % (cbw * cbh);
+            comp = 1 + j / (cbw * cbh), lbx = k % cbw, lby = k / cbw;
         }
-        if (comp < 3) {
-            const JPlane pl = planes[im.first_plane + comp];
-            // position in the plane's block grid (the chroma grid of LDS begins one block before the tile)
-            const int bx = comp == 0 ? (int)(tx * FT_MX * 2 + lbx) : (int)(tx * FT_MX + lbx) - 1, by = comp == 0 ? (int)(ty * FT_MY * 2 + lby) : (int)(ty * FT_MY + lby) - 1;
-            if (bx >= 0 && by >= 0 && bx < (int)pl.blocks_w && by < (int)pl.blocks_h) {
-                uint2 rows[8];
-                idct_block<FL>(coef, qts, pl, (uint32_t)by * pl.blocks_w + (uint32_t)bx, (uint32_t)bx, (uint32_t)by, refs, corr, dcbits, rows);
-                uint8_t *dst = comp == 0 ? s_y + (lby * 8) * FT_LW + lbx * 8 : s_c[comp - 1] + (lby * 8) * FT_CW + lbx * 8;
-                const int pitch = comp == 0 ? FT_LW : FT_CW;
+        const JPlane pl = planes[im.first_plane + comp];
+        const int bx = comp == 0 ? (int)(tx * FT_LBW + lbx) : cbx0 + (int)lbx, by = comp == 0 ? (int)(ty * FT_LBH + lby) : cby0 + (int)lby;
+        if (bx >= 0 && by >= 0 && bx < (int)pl.blocks_w && by < (int)pl.blocks_h) {
+            uint2 rows[8];
+            idct_block<FL>(coef, qts, pl, (uint32_t)by * pl.blocks_w + (uint32_t)bx, (uint32_t)bx, (uint32_t)by, refs, corr, dcbits, rows);
+            const uint32_t pitch = comp == 0 ? (uint32_t)FT_LW : cpitch;
+            uint8_t *dst = comp == 0 ? s_y + (lby * 8) * FT_LW + lbx * 8 : s_c[comp - 1] + (lby * 8) * cpitch + lbx * 8;
 #pragma unroll
-                for (int y = 0; y < 8; y++) *reinterpret_cast<uint2 *>(dst + y * pitch) = rows[y];
-            }
+            for (int y = 0; y < 8; y++) *reinterpret_cast<uint2 *>(dst + y * pitch) = rows[y];
         }
     }
     __syncthreads();
     // ---- 8 pixels of a row per lane and turn, as jpeg_color_kernel makes them; the chroma tiles stand for their planes (a pointer such that
     // the plane's coordinates land in the tile: the filters clamp to the plane's own edges, which lie inside the tile or its ring)
-    const int cy0 = (int)(ty * FT_MY * 8) - 8, cx0 = (int)(tx * FT_MX * 8) - 8;  // plane coordinates of the chroma tiles' first sample
-    const uint8_t *vcb = s_c[0] - (cy0 * FT_CW + cx0), *vcr = s_c[1] - (cy0 * FT_CW + cx0);
+    const int cy0 = cby0 * 8, cx0 = cbx0 * 8;  // plane coordinates of the chroma tiles' first sample
+    const uint8_t *vcb = s_c[0] - (cy0 * (int)cpitch + cx0), *vcr = s_c[1] - (cy0 * (int)cpitch + cx0);
     const int cols = (int)im.pitch[1];
     uint8_t *img_out = out + im.out_off;
 #pragma unroll
@@ -445,8 +445,8 @@ __global__ void __launch_bounds__(256) jpeg_fused_kernel(const int16_t *__restri
         const uint2 yy = *reinterpret_cast<const uint2 *>(s_y + row * FT_LW + xg * 8);
         int ys[8], cb[8], cr[8];
         bytes4(yy.x, ys), bytes4(yy.y, ys + 4);
-        chroma8<FL>(vcb, FT_CW, (int)im.cw, (int)im.ch, x0, y, 2, 2, cb, cols);
-        chroma8<FL>(vcr, FT_CW, (int)im.cw, (int)im.ch, x0, y, 2, 2, cr, cols);
+        chroma8<FL>(vcb, (int)cpitch, (int)im.cw, (int)im.ch, x0, y, (int)hs, (int)vs, cb, cols);
+        chroma8<FL>(vcr, (int)cpitch, (int)im.cw, (int)im.ch, x0, y, (int)hs, (int)vs, cr, cols);
         uint32_t l[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {

@@ -402,12 +402,12 @@ int build_descriptors(Jobs &jobs, const std::vector<uint32_t> &idx, size_t first
         JImage im;
         memset(&im, 0, sizeof im);
         D.plane_of[r] = D.n_planes;
-        // 4:2:0 and only the hasher reads the pixels: IDCT + upsampling + colour in one kernel, the sample planes never exist
-        const bool fused = fuse && f.ncomp == 3 && out_channels(f, rgb_wanted) == 1 && f.comp[0].H == 2 && f.comp[0].V == 2 && f.comp[1].H == 1 && f.comp[1].V == 1 &&
+        // three components (luma sampled once or twice the chroma) and only the hasher reads the pixels: IDCT + upsampling + colour in one kernel
+        const bool fused = fuse && f.ncomp == 3 && out_channels(f, rgb_wanted) == 1 && f.comp[0].H <= 2 && f.comp[0].V <= 2 && f.comp[1].H == 1 && f.comp[1].V == 1 &&
                            f.comp[2].H == 1 && f.comp[2].V == 1;
         im.fused = fused;
         im.first_plane = D.n_planes - sub_first_plane;
-        im.mcus_x = f.mcus_x, im.mcus_y = f.mcus_y;
+        im.tiles_x = (f.comp[0].blocks_w + 15) / 16, im.tiles_y = (f.comp[0].blocks_h + 7) / 8;
         for (int c = 0; c < f.ncomp; c++) {
             const rphj::Comp &kc = f.comp[c];
             JPlane pl;
@@ -473,7 +473,7 @@ int reconstruct_and_hash(rph_ctx *ctx, JpegPipe &P, int b, Slot &S, Jobs &jobs, 
     for (uint32_t q = i0; q < i1; q++)
         if (hi_all[q].fused) {
             n_fused++;
-            max_tiles = std::max(max_tiles, ((hi_all[q].mcus_x + 7) / 8) * ((hi_all[q].mcus_y + 3) / 4));
+            max_tiles = std::max(max_tiles, hi_all[q].tiles_x * hi_all[q].tiles_y);
         }
     if (n_fused < i1 - i0) {  // (the plane kernels skip the images the fused kernel takes)
         RPH_TRY(rph_jpeg_launch_idct(flavour, max_blocks, p1 - p0, s, d_coef, dq, dp, P.d_planes[b], D.d_refs, D.d_corr, D.d_dcbits));
