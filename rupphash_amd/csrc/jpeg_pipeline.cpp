@@ -1089,7 +1089,6 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 RPH_TRY(rph_jpeg_launch_segments(s, S.stream_bytes.d, reinterpret_cast<const HImage *>(S.meta.d + off_himg), reinterpret_cast<const SegFile *>(S.meta.d + off_segf),
                                                  (uint32_t)seg_files.size(), d_segs, n_segs, ctx->jpeg_seg_bytes, d_segtab, 8,
                                                  reinterpret_cast<const rphj::DeviceLut *>(S.meta.d + off_luts), (uint32_t)luts.size(), reinterpret_cast<HItem *>(S.meta.d + off_items)));
-                if (tr) rph_jpeg_debug_segment_stats(s, d_segtab, n_segs);
             }
             lap(t_seg);
             // The coefficients start from zero -- unless the walk writes whole blocks and covers every block of the chunk: sequential files of
@@ -1112,6 +1111,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 RPH_TRY(reconstruct_and_hash(ctx, P, b, S, jobs, idx, first, D, r0, r1, d_coef, flavour, out, s));
             }
             lap(t_rec);
+            if (tr && n_segs) rph_jpeg_debug_segment_stats(s, S.d_segwork + align_up((size_t)n_segs * sizeof(SegState), 16), n_segs);  // (behind the timed phases)
             if (tr)
                 fprintf(stderr, "[rph_jpeg] chunk of %zu files in %zu lanes (%.1f MB of entropy bytes, %.2f GB of coefficients, %zu tables, %zu sub-batches): prepare %.1f ms, "
                                 "descriptors %.1f ms, upload %.1f ms, %u segments %.1f ms, zero %.1f ms, walk %.1f ms, reconstruct + hash %.1f ms\n",

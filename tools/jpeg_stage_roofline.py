@@ -20,7 +20,7 @@ for kind in ("small", "photos", "prog"):
     ms = {}
     for r in csv.DictReader(open(os.path.join(d, f"{kind}_kernel_stats.csv"))):
         name = r["Name"]
-        for key in ("jpeg_huff_kernel", "jpeg_prog_kernel", "jpeg_sync_kernel", "jpeg_seg_items_kernel", "jpeg_seg_map_kernel", "jpeg_idct_kernel", "jpeg_color_kernel",
+        for key in ("jpeg_huff_kernel", "jpeg_prog_kernel", "jpeg_sync_kernel", "jpeg_seg_items_kernel", "jpeg_seg_map_kernel", "jpeg_idct_kernel", "jpeg_color_kernel", "jpeg_fused_kernel",
                     "pdq_fused512_kernel", "pdq_stream_kernel", "resize_mfma_kernel", "resize_fused_kernel", "fillBuffer", "copyBuffer"):
             if key in name:
                 ms[key] = ms.get(key, 0.0) + float(r["TotalDurationNs"]) / 1e6 / calls
@@ -34,6 +34,9 @@ for kind in ("small", "photos", "prog"):
             stages[label] = {"kernel": kernel, "ms_per_call": round(ms[kernel], 3), "algorithmic_bytes_per_call": int(nbytes), "bound": "hbm", "achieved_GBs": round(gbs, 1),
                              "peak_GBs": HBM / 1e9, "frac": round(gbs * 1e9 / HBM, 4), "bytes": what}
 
+    hbm_stage("reconstruction", "jpeg_fused_kernel", blocks * 128 + px * 1.0,
+              "IDCT + upsampling + colour + Rec.601 luma in one kernel: 128 B of coefficients read per 8x8 block, 1 B of luma written per pixel (the ring of chroma blocks a tile "
+              "reads beyond its own is not counted)")
     hbm_stage("idct", "jpeg_idct_kernel", blocks * 192, "128 B of coefficients read + 64 B of samples written per 8x8 block")
     hbm_stage("upsampling_and_colour", "jpeg_color_kernel", ppx * 1.5 + px * 1.0, "Y + Cb + Cr samples read (1.5 B per pixel at 4:2:0), Rec.601 luma written (1 B per pixel: the hasher is the only reader)")
     if w > 512 or h > 512:
