@@ -180,13 +180,33 @@ constexpr uint32_t CHUNK_MAX_IMAGES = 4096;               // host entropy
 constexpr size_t SUB_MAX_IMAGES = 16384;                  // images per reconstruction sub-batch (grid.y of the kernels: 3 planes each)
 constexpr uint32_t DEVICE_ENTROPY_MIN_FILES = 512;        // automatic mode: below this many lanes (files, or restart intervals) the host decodes (latency)
 
-// Huffman tables of a chunk, one per distinct content (most files of a collection share the four Annex K tables)
+// Huffman tables of a chunk, one per distinct content (most sequential files of a collection share the four Annex K tables; a
+// progressive file brings a dozen of its own).  Sixteen threads ask at once: the index is cut into 64 shards by the tables' hash, each
+// with a lock of its own, and the tables themselves lie in blocks that never move (an id is a slot, taken with an atomic add).
 struct TableStore {
-    std::mutex mu;
-    std::vector<rphj::DeviceLut> luts;
-    std::vector<rphj::TableSpec> specs;
-    std::unordered_multimap<uint64_t, uint32_t> by_hash;
+    static constexpr uint32_t SHARDS = 64, BLOCK = 1024, MAX_BLOCKS = 8192;
+    struct Shard {
+        std::mutex mu;
+        std::unordered_multimap<uint64_t, uint32_t> by_hash;
+    } shard[SHARDS];
+    std::mutex grow_mu;
+    std::atomic<rphj::DeviceLut *> lut_block[MAX_BLOCKS];
+    std::atomic<rphj::TableSpec *> spec_block[MAX_BLOCKS];
+    std::atomic<uint32_t> count{0};
     uint64_t serial = next_serial();  // tells a thread's cache of ids that it belongs to another store
+    TableStore()
+    {
+        for (uint32_t b = 0; b < MAX_BLOCKS; b++) lut_block[b].store(nullptr, std::memory_order_relaxed), spec_block[b].store(nullptr, std::memory_order_relaxed);
+    }
+    ~TableStore()
+    {
+        for (uint32_t b = 0; b < MAX_BLOCKS; b++) {
+            delete[] lut_block[b].load(std::memory_order_relaxed);
+            delete[] spec_block[b].load(std::memory_order_relaxed);
+        }
+    }
+    TableStore(const TableStore &) = delete;
+    TableStore &operator=(const TableStore &) = delete;
     static uint64_t next_serial()
     {
         static std::atomic<uint64_t> n{1};
@@ -196,16 +216,35 @@ struct TableStore {
     {
         return a.total == b.total && memcmp(a.counts + 1, b.counts + 1, 16) == 0 && memcmp(a.symbols, b.symbols, a.total) == 0;
     }
-    uint32_t find_locked(uint64_t h, const rphj::TableSpec &t) const
+    const rphj::TableSpec &spec(uint32_t id) const { return spec_block[id / BLOCK].load(std::memory_order_acquire)[id % BLOCK]; }
+    uint32_t size() const { return count.load(std::memory_order_acquire); }
+    void copy_luts(rphj::DeviceLut *dst) const  // (when the threads are done)
     {
-        auto range = by_hash.equal_range(h);
+        const uint32_t n = size();
+        for (uint32_t first = 0; first < n; first += BLOCK)
+            memcpy(dst + first, lut_block[first / BLOCK].load(std::memory_order_acquire), (size_t)std::min(BLOCK, n - first) * sizeof(rphj::DeviceLut));
+    }
+    uint32_t find_locked(const Shard &sh, uint64_t h, const rphj::TableSpec &t) const
+    {
+        auto range = sh.by_hash.equal_range(h);
         for (auto it = range.first; it != range.second; ++it)
-            if (same(specs[it->second], t)) return it->second;
+            if (same(spec(it->second), t)) return it->second;
         return UINT32_MAX;
     }
-    // Every file of a call asks for its four tables, from sixteen threads: a collection has a handful of distinct tables, so each thread
-    // remembers the last few it was given (no lock at all for them); a table nobody has seen is built OUTSIDE the lock (progressive files
-    // carry tables of their own, ten per file: building them under the lock serialised the whole preparation).
+    uint32_t new_slot()  // UINT32_MAX: full (the file then goes to the host decoder)
+    {
+        const uint32_t id = count.fetch_add(1, std::memory_order_acq_rel);
+        if (id >= BLOCK * MAX_BLOCKS) return UINT32_MAX;
+        const uint32_t b = id / BLOCK;
+        if (!lut_block[b].load(std::memory_order_acquire) || !spec_block[b].load(std::memory_order_acquire)) {
+            std::lock_guard<std::mutex> lock(grow_mu);
+            if (!spec_block[b].load(std::memory_order_acquire)) spec_block[b].store(new rphj::TableSpec[BLOCK], std::memory_order_release);
+            if (!lut_block[b].load(std::memory_order_acquire)) lut_block[b].store(new rphj::DeviceLut[BLOCK], std::memory_order_release);
+        }
+        return id;
+    }
+    // Every file of a call asks for its tables, from sixteen threads: each thread remembers the last few it was given (no lock at all
+    // for them: the four tables a collection of sequential files shares); a table nobody has seen is built OUTSIDE the lock.
     static uint32_t intern(void *self, const rphj::TableSpec &t)
     {
         TableStore &T = *static_cast<TableStore *>(self);
@@ -225,21 +264,23 @@ struct TableStore {
         }
         for (int i = 0; i < recent.n; i++)
             if (recent.hash[i] == h && same(recent.spec[i], t)) return recent.id[i];
+        Shard &sh = T.shard[(h >> 7) % SHARDS];
         uint32_t id;
         {
-            std::lock_guard<std::mutex> lock(T.mu);
-            id = T.find_locked(h, t);
+            std::lock_guard<std::mutex> lock(sh.mu);
+            id = T.find_locked(sh, h, t);
         }
         if (id == UINT32_MAX) {
             rphj::DeviceLut L;
             if (rphj::build_device_lut(t, L) != RPH_OK) return UINT32_MAX;
-            std::lock_guard<std::mutex> lock(T.mu);
-            id = T.find_locked(h, t);  // (another thread may have been quicker)
+            std::lock_guard<std::mutex> lock(sh.mu);
+            id = T.find_locked(sh, h, t);  // (another thread may have been quicker)
             if (id == UINT32_MAX) {
-                T.luts.push_back(L);
-                T.specs.push_back(t);
-                id = (uint32_t)T.luts.size() - 1;
-                T.by_hash.emplace(h, id);
+                id = T.new_slot();
+                if (id == UINT32_MAX) return UINT32_MAX;
+                T.lut_block[id / BLOCK].load(std::memory_order_acquire)[id % BLOCK] = L;
+                T.spec_block[id / BLOCK].load(std::memory_order_acquire)[id % BLOCK] = t;
+                sh.by_hash.emplace(h, id);
             }
         }
         const int slot = recent.n < 8 ? recent.n++ : (recent.next = (recent.next + 1) & 7);
@@ -868,22 +909,28 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                     // An AC scan follows up to two of them (the longest) block by block (PScan::chase); the others must have ended.
                     ps.chase[0] = ps.chase[1] = PSCAN_NONE;
                     ps.wait_first = (uint32_t)pwaits.size();
-                    auto comps = [](const PScan &x) { uint32_t m = 0; for (uint32_t c = 0; c < x.ns && c < 3; c++) m |= 1u << x.ci[c]; return m; };
-                    std::vector<uint32_t> deps;
+                    uint32_t my_comps = 0;
+                    for (uint32_t c = 0; c < ps.ns && c < 3; c++) my_comps |= 1u << ps.ci[c];
+                    uint32_t deps[rphj::MAX_PROG_SCANS], n_deps = 0;
                     for (size_t q = p0; q < pscans.size(); q++) {
                         const PScan &e = pscans[q];
-                        if ((comps(e) & comps(ps)) && e.ss <= ps.se && ps.ss <= e.se) deps.push_back((uint32_t)q);
+                        uint32_t its = 0;
+                        for (uint32_t c = 0; c < e.ns && c < 3; c++) its |= 1u << e.ci[c];
+                        if ((its & my_comps) && e.ss <= ps.se && ps.ss <= e.se) deps[n_deps++] = (uint32_t)q;
                     }
-                    if (ps.ss > 0) {  // (AC scans of one component walk the same raster of blocks)
-                        std::stable_sort(deps.begin(), deps.end(), [&](uint32_t a, uint32_t b) { return pscans[a].len > pscans[b].len; });
-                        for (size_t d = 0; d < deps.size(); d++) {
-                            if (d < 2)
-                                ps.chase[d] = deps[d];
-                            else
-                                pwaits.push_back(deps[d]);
+                    if (ps.ss > 0) {  // (AC scans of one component walk the same raster of blocks): the two longest are followed
+                        for (int k = 0; k < 2; k++) {
+                            uint32_t best = PSCAN_NONE;
+                            for (uint32_t d = 0; d < n_deps; d++)
+                                if (deps[d] != PSCAN_NONE && (best == PSCAN_NONE || pscans[deps[d]].len > pscans[deps[best]].len)) best = d;
+                            if (best == PSCAN_NONE) break;
+                            ps.chase[k] = deps[best];
+                            deps[best] = PSCAN_NONE;
                         }
+                        for (uint32_t d = 0; d < n_deps; d++)
+                            if (deps[d] != PSCAN_NONE) pwaits.push_back(deps[d]);
                     } else if (ps.ah == 0) {
-                        pwaits.insert(pwaits.end(), deps.begin(), deps.end());
+                        pwaits.insert(pwaits.end(), deps, deps + n_deps);
                     }  // (a DC refinement scan writes its bits beside the coefficients and reads nothing: it waits for nobody)
                     ps.wait_count = (uint32_t)pwaits.size() - ps.wait_first;
                     pscans.push_back(ps);
@@ -1001,7 +1048,11 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             sf.first_item = n_items;
             n_items += sf.n_segs;
         }
-        const std::vector<rphj::DeviceLut> &luts = store.luts;
+        struct {
+            uint32_t n;
+            size_t size() const { return n; }
+            bool empty() const { return n == 0; }
+        } luts{store.size()};  // (the tables' count: they lie in the store's blocks)
         // ---- meta buffer: reconstruction descriptors | HImage | order | tables
         const size_t recon_bytes = m * (3 * sizeof(JPlane) + sizeof(JImage) + 3 * 128);
         // (the items of the segments exist on the device only: d_meta has room for them, the upload stops before them)
@@ -1047,7 +1098,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
         memcpy(S.meta.h + off_himg, himgs.data(), m * sizeof(HImage));
         memcpy(S.meta.h + off_items, items.data(), items.size() * sizeof(HItem));
         memcpy(S.meta.h + off_order, order.data(), order.size() * 4);
-        if (!luts.empty()) memcpy(S.meta.h + off_luts, luts.data(), luts.size() * sizeof(rphj::DeviceLut));
+        if (!luts.empty()) store.copy_luts(reinterpret_cast<rphj::DeviceLut *>(S.meta.h + off_luts));
         if (n_segs) memcpy(S.meta.h + off_segf, seg_files.data(), seg_files.size() * sizeof(SegFile));
         if (!prog_order.empty()) {
             memcpy(S.meta.h + off_pscan, pscans.data(), pscans.size() * sizeof(PScan));

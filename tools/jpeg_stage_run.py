@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/jpeg_stage_run.py small|photos|prog [calls] -- the JPEG leg of bench.py as a bare loop of `calls` rph_jpeg_pdq_hash_batch calls, to be run
+"""tools/jpeg_stage_run.py small|smallprog|photos|prog [calls] -- the JPEG leg of bench.py as a bare loop of `calls` rph_jpeg_pdq_hash_batch calls, to be run
 under rocprofv3 --kernel-trace --stats (tools/jpeg_stage_profile.sh): every kernel launch of the run belongs to the one workload, so a stage's
 time per call is its TotalDurationNs / calls.  Prints one JSON line with the counts the per-stage rooflines are priced with."""
 import io
@@ -28,12 +28,12 @@ def enc(a, **kw):
     return b.getvalue()
 
 
-if kind == "small":
+if kind in ("small", "smallprog"):
     distinct, n, w, h = 4096, 100_000, 512, 512
     base = []
     with ThreadPoolExecutor(threads) as pool:
         for first in range(0, distinct, 256):
-            base += list(pool.map(lambda a: enc(a, quality=85, subsampling=2), eng.synth_images(first, 256)))
+            base += list(pool.map(lambda a: enc(a, quality=85, subsampling=2, progressive=(kind == "smallprog")), eng.synth_images(first, 256)))
 else:
     distinct, n, w, h = 64, 20_000, 1265, 850
     im = Image.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "bench.jpg"))
