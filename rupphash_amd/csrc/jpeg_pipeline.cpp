@@ -640,6 +640,7 @@ int run_host_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, const std::vector<ui
                 Job &j = jobs[idx[i]];
                 if (j.status == RPH_OK) j.status = rphj::decode_coefficients(j.data, j.len, j.frame, h_coef + j.first_block * 64);
             });
+        RPH_JPEG_STAMP("lane %d: chunk %d buffers sized", b, k);
         ChunkDesc D;
         std::vector<size_t> subs;
         RPH_TRY(build_descriptors(jobs, idx, first, last, flavour, out.pixels != nullptr, SIZE_MAX / 256, S.meta.h, 0, D, subs));
@@ -986,6 +987,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 item_len.push_back(end > off ? end - off : 0);
             }
         }
+        RPH_JPEG_STAMP("lane %d: chunk %d items listed", b, k);
         // The lanes of the launch: 64 files of one scan script make a batch, and wave k of a batch walks the k-th scan of each of them -- one
         // kind of scan per wave, and a scan's producers in earlier workgroups of the same launch, which start first (jpeg_kernels.hip).
         std::vector<uint32_t> pitems;
@@ -1038,6 +1040,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
             for (const Wave &w : waves)
                 for (uint32_t l = 0; l < 64; l++) pitems.push_back(l < w.count ? himgs[sig[w.first + l].second].pscan_first + w.k : PSCAN_NONE);
         }
+        RPH_JPEG_STAMP("lane %d: chunk %d waves ordered", b, k);
         std::vector<uint32_t> order(items.size());
         for (uint32_t t = 0; t < order.size(); t++) order[t] = t;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return item_len[a] > item_len[b]; });
@@ -1118,6 +1121,7 @@ int run_device_entropy(rph_ctx *ctx, JpegPipe &P, Jobs &jobs, std::vector<uint32
                 D.d_dcbits = S.d_pdc;
             }
         }
+        RPH_JPEG_STAMP("lane %d: chunk %d descriptors written", b, k);
         // ---- device: streams up, zeroed coefficients, the walk, then reconstruction + hashing sub-batch by sub-batch
         const double t_desc = now_ms();
         const bool tr = trace_on();  // RPH_JPEG_TRACE: synchronise after every phase and print where the time goes (stderr)
